@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the post-CNN stereo pipeline (stereo_predict, main.lua:929-1082)
+on MI355X, the `-a time` analogue of the reference (main.lua:1140-1167).
+
+A "step" is one stereo pair through the hot path (cost volume -> CBCA -> SGM -> arg-min ->
+LR check -> interpolation -> sub-pixel -> median -> range-gated Gaussian) with the inputs
+(normalised images + features or raw volumes) already resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config kitti_fast|kitti_slow|mb_slow]
+
+Default workload = BASELINE.json configs[1]: KITTI 2012 fast, 370x1226, disp_max 228.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank processes its own pair
+per step (weak scaling, pairs are independent) and the finished disparity maps are gathered
+with one RCCL all-gather per step -- the only collective on the path.
+
+Prints ONE JSON line (rank 0).  `value` = Mega-pixel-disparities / s = n_gpus * 2 volumes *
+H*W*D / 1e6 / seconds-per-step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CONFIGS = {
+    # name: (preset, H, W, D, C or 0 for raw volumes, BASELINE.json config string)
+    "kitti_fast": ("kitti_fast", 370, 1226, 228, 64, "KITTI 2012 fast, 370x1226 disp_max=228"),
+    "kitti_slow": ("kitti_slow", 370, 1226, 228, 0, "KITTI 2012 accurate (from raw volumes), 370x1226 disp_max=228"),
+    "mb_slow": ("mb_slow", 1000, 1500, 256, 0, "Middlebury-size accurate (from raw volumes), 1000x1500 disp_max=256"),
+    "tiny": ("kitti_fast", 48, 160, 32, 16, "tiny plumbing case"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(preset, H, W, D, C):
+    """fp32, V = 4*D*H*W, F = 4*C*H*W.  Per PAIR (two volumes)."""
+    V = 4.0 * D * H * W
+    F = 4.0 * C * H * W
+    b = dict(join=(2 * F + 2 * V) if C else 0.0,
+             cbca=2 * (preset["cbca_i1"] + preset["cbca_i2"]) * 2 * V,
+             sgm=2 * 11 * V * preset["sgm_i"],
+             argmin=2 * V)
+    b["total"] = sum(b.values())
+    return b
+
+
+def make_inputs(cfg, rank, device):
+    import torch
+    from util import features, raw_volumes, smooth_pair
+    preset, H, W, D, C, _ = cfg
+    x0, x1 = smooth_pair(H, W, D, seed=1234 + rank)
+    xb = torch.from_numpy(np.stack([x0, x1])[:, None]).to(device)
+    host = dict(x0=x0, x1=x1)
+    if C:
+        f = features(C, H, W, seed=42 + rank)
+        host["feat"] = f
+        kw = dict(feat=torch.from_numpy(f).to(device))
+    else:
+        vl, vr = raw_volumes(D, H, W, seed=7 + rank)
+        host["raw"] = (vl, vr)
+        kw = dict(raw=(torch.from_numpy(vl).to(device), torch.from_numpy(vr).to(device)))
+    return xb, kw, host
+
+
+def cpu_baseline(cfg, host, budget_rows):
+    """The oracle (a faithful CPU restatement of the reference, oracle/mc_oracle.c) on a bounded
+    sample of the same workload: a band of `rows` image rows at full width and full disp_max."""
+    from oracle import cpu_oracle
+    import mc_cnn_amd as mc
+    preset, H, W, D, C, _ = cfg
+    rows = min(H, budget_rows)
+    prm = dict(mc.PRESETS[preset])
+    x0, x1 = host["x0"][:rows], host["x1"][:rows]
+    kw = {}
+    if C:
+        kw = dict(featL=host["feat"][0][:, :rows], featR=host["feat"][1][:, :rows])
+    else:
+        kw = dict(rawL=host["raw"][0][:, :rows], rawR=host["raw"][1][:, :rows])
+    cpu_oracle.build()
+    t0 = time.perf_counter()
+    cpu_oracle.stereo_predict(prm, x0, x1, D, **kw)
+    dt = time.perf_counter() - t0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    cores = int(os.environ.get("OMP_NUM_THREADS", cores))
+    return dict(value=round(2.0 * rows * W * D / 1e6 / dt, 3), unit="MPix-disp/s", cores=cores, kind="port",
+                sample="oracle stereo_predict on a %dx%dx%d band (%d of %d rows) of the same pair, 1 run, %.1f s" %
+                       (rows, W, D, rows, H, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="kitti_fast", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline band (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mc_cnn_amd as mc
+    from mc_cnn_amd.predict import Workspace
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" %
+              (args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    cfg = CONFIGS[args.config]
+    preset_name, H, W, D, C, cfg_name = cfg
+    prm = dict(mc.PRESETS[preset_name])
+    xb, kw, host = make_inputs(cfg, rank, device)
+    ws = Workspace(prm, D, H, W, device)
+    out = torch.empty((1, 1, H, W), dtype=torch.float32, device=device)
+    gathered = torch.empty((world, H, W), dtype=torch.float32, device=device) if world > 1 else None
+
+    def step():
+        mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, **kw)
+        if world > 1:  # the path's only exchange: finished disparity maps (H*W*4 B per GPU) over xGMI
+            dist.all_gather_into_tensor(gathered, out.view(1, H, W))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * 2.0 * H * W * D / 1e6 / (dt / args.steps)
+
+    # live per-stage HIP-event timing (same stream) for the roofline of the dominant kernel
+    roof = None
+    stage = None
+    if rank == 0:
+        reps = max(3, min(10, args.steps))
+        acc = {}
+        for _ in range(reps):
+            r = mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, timed=True, **kw)
+            for k, v in r["stage_ms"].items():
+                acc[k] = acc.get(k, 0.0) + v / reps
+        stage = {k: round(v, 4) for k, v in acc.items() if k != "_"}
+        ab = algorithmic_bytes(prm, H, W, D, C)
+        dom = "cbca" if ab["cbca"] > ab["sgm"] else "sgm"
+        n_launch = {"sgm": 4 * prm["sgm_i"], "cbca": 2 * (prm["cbca_i1"] + prm["cbca_i2"])}[dom]
+        achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9 if acc[dom] > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(dom)
+        roof = dict(bound="hbm", kernel={"sgm": "sgm_pass_kernel (4 direction sweeps over both volumes)",
+                                         "cbca": "cbca kernel (one launch per iteration per volume)"}[dom],
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                    traffic=traffic, launches_per_step=n_launch,
+                    algorithmic_bytes_per_launch=round(ab[dom] / n_launch),
+                    avg_launch_ms=round(acc[dom] / n_launch, 4),
+                    pipeline_frac=round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rows = args.cpu_rows or {"kitti_fast": 370, "kitti_slow": 370, "mb_slow": 8, "tiny": 48}[args.config]
+        cpu = cpu_baseline(cfg, host, rows)
+
+    if rank == 0:
+        line = {
+            "metric": "Mega-pixel-disparities/sec (cost-vol+CBCA+SGM+post, end-to-end disp)",
+            "value": round(value, 1), "unit": "MPix-disp/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg_name, "H": H, "W": W, "disp_max": D, "feature_channels": C,
+                       "params": preset_name, "pairs_per_step": world, "parallelism": "one pair per GPU",
+                       "end_to_end_ms_per_pair": round(ms_per_step, 4)},
+            "stage_ms": stage, "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,215 @@
+/*
+ * mc_adcensus.h -- C ABI of libmcadcensus.so, the MI355X (gfx950) replacement
+ * for the hot path of jzbontar/mc-cnn's libadcensus.so.
+ *
+ * The reference exposes this path as a Lua-C module: `require 'libadcensus'`
+ * registers the table `adcensus` with the functions listed in funcs[]
+ * (adcensus.cu:2061-2096), each `int f(lua_State*)` taking torch.CudaTensor
+ * userdata.  A LuaJIT-FFI shim (mc-cnn_amd/lua/adcensus.lua)
+ * rebuilds that table on top of the entry points below, so `main.lua -a
+ * predict` keeps its call sites (main.lua:929-1082).  Each declaration cites
+ * the reference binding it replaces.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to contiguous fp32 data (the reference
+ *     reads raw THCudaTensor_data and assumes contiguity, adcensus.cu:97-111);
+ *   - dims are passed explicitly (the reference reads them from tensor sizes);
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are
+ *     asynchronous, never synchronise the device and never allocate, except
+ *     mc_sgm2 / mc_predict which use caller-provided workspaces;
+ *   - return 0 on success, a hipError_t (> 0) for a runtime failure or
+ *     MC_EINVAL (< 0) for a bad argument; mc_last_error() returns a
+ *     thread-local message (the reference raises luaL_error after
+ *     cudaPeekAtLastError, adcensus.cu:31-36; the Lua shim turns rc != 0
+ *     into error()).
+ *   - volumes are (D,H,W) "DHW" unless a name says hwd = (H,W,D), D contiguous.
+ *   - `direction` is -1 for the left-referenced volume (partner x-d) and +1
+ *     for the right-referenced one (partner x+d), as in main.lua:986.
+ */
+#ifndef MC_ADCENSUS_H
+#define MC_ADCENSUS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+
+#define MC_ABI_VERSION 1
+#define MC_EINVAL (-22)
+#define MC_SGM_MAX_D 512   /* reference: __shared__ float[400], adcensus.cu:574 */
+#define MC_JOIN_MAX_C 128  /* reference: float L_cache[128], adcensus.cu:1460-1461 */
+
+/* adcensus.version (adcensus.cu funcs[]) analogue. */
+int mc_version(void);
+const char *mc_last_error(void);
+
+/* ---- cost volume ------------------------------------------------------ */
+
+/* cutorch :fill(0/0) of the volumes, main.lua:933,939,946,966. */
+int mc_fill_nan(float *p, int64_t n, void *stream);
+
+/* adcensus.StereoJoin(input_L, input_R, output_L, output_R), adcensus.cu:1479-1498
+ * (kernel 1455-1477).  feat*: (C,H,W), C <= 128; vol*: (D,H,W).  Writes only
+ * voxels with x-d >= 0 (volL[d,y,x], volR[d,y,x-d]); the rest keeps the
+ * caller's fill, as in the reference. */
+int mc_stereo_join(const float *featL, const float *featR, float *volL, float *volR,
+                   int C, int D, int H, int W, void *stream);
+
+/* adcensus.ad(x0, x1, out, direction), adcensus.cu:95-114 (kernel 62-93). x: (H,W). */
+int mc_ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, void *stream);
+
+/* adcensus.census(x0, x1, out, direction), adcensus.cu:155-175 (kernel 117-153). x: (Cimg,H,W). */
+int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W,
+              int direction, void *stream);
+
+/* fix_border(net, vol, direction), main.lua:922-927: n = (window-1)/2 columns. */
+int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream);
+
+/* ---- cross-based cost aggregation -------------------------------------- */
+
+/* adcensus.cross(x0, out, L1, tau1), adcensus.cu:324-341 (kernel 280-322).
+ * img (H,W) -> arms (4,H,W): exclusive arm ends for -x,+x,-y,+y. */
+int mc_cross(const float *img, float *arms, int H, int W, int L1, float tau1, void *stream);
+
+/* adcensus.cbca(x0c, x1c, vol_in, vol_out, direction), adcensus.cu:379-400
+ * (kernel 343-377).  Reference accumulation order (yy outer, xx inner, one
+ * fp32 accumulator, IEEE divide) is kept, so results are bit-identical. */
+int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
+            int D, int H, int W, int direction, void *stream);
+
+/* ---- semiglobal matching ------------------------------------------------ */
+
+/* Bytes of scratch mc_sgm2 needs in `tmp` (edge-class maps; the reference's
+ * tmp (W,D) line state lives in registers here). */
+size_t mc_sgm2_tmp_bytes(int H, int W, int D);
+
+/* adcensus.sgm2(x0, x1, input, output, tmp, pi1, pi2, tau_so, alpha1, sgm_q1,
+ * sgm_q2, direction), adcensus.cu:620-697 (kernels 535-618).  x0,x1: (H,W);
+ * in_hwd/out_hwd: (H,W,D); the four directional costs are ADDED to out_hwd in
+ * the reference's order (right, left, down, up), so the caller zeroes it first
+ * (main.lua:1014).  D <= MC_SGM_MAX_D.  `tmp` must hold mc_sgm2_tmp_bytes();
+ * pass tmp_bytes so that an undersized buffer is rejected, not overrun.
+ * Contract: NaNs in a pixel's cost vector form a (possibly empty) tail in d
+ * and d=0 is finite -- true for every volume the pipeline produces. */
+int mc_sgm2(const float *x0, const float *x1, const float *in_hwd, float *out_hwd,
+            void *tmp, size_t tmp_bytes, int H, int W, int D,
+            float pi1, float pi2, float tau_so, float alpha1, float sgm_q1, float sgm_q2,
+            int direction, void *stream);
+
+/* vol:transpose(2,3):transpose(3,4):clone(), main.lua:1008: (D,H,W) -> (H,W,D). */
+int mc_dhw_to_hwd(const float *in, float *out, int D, int H, int W, void *stream);
+/* vol:copy(out:transpose(3,4):transpose(2,3)):div(4), main.lua:1019-1020:
+ * (H,W,D) -> (D,H,W), every element multiplied by `scale` (0.25 = /4, exact). */
+int mc_hwd_to_dhw(const float *in, float *out, int D, int H, int W, float scale, void *stream);
+/* vol:copy(out):div(4), main.lua:1017 (any layout): out[i] = in[i] * scale. */
+int mc_scale(const float *in, float *out, int64_t n, float scale, void *stream);
+
+/* ---- disparity and post-processing ------------------------------------- */
+
+/* _, d = torch.min(vol, 2); d:add(-1), main.lua:1049-1050 (cutorch).  0-based
+ * argmin over d as float; first strict minimum, NaN never wins (the in-repo
+ * convention of spatial_argmin, adcensus.cu:251-260). */
+int mc_argmin(const float *vol, float *disp, int D, int H, int W, void *stream);
+
+/* adcensus.spatial_argmin(input, output), adcensus.cu:264-278: 1-based. */
+int mc_spatial_argmin(const float *vol, float *out, int D, int H, int W, void *stream);
+
+/* adcensus.outlier_detection(d0, d1, outlier, disp_max), adcensus.cu:901-918 (kernel 878-899). */
+int mc_outlier_detection(const float *d0, const float *d1, float *outlier, int H, int W,
+                         int disp_max, void *stream);
+
+/* adcensus.interpolate_occlusion(d0, outlier) -> new tensor, adcensus.cu:1107-1125
+ * (kernel 1079-1105).  `out` is caller-provided here; the Lua shim allocates it. */
+int mc_interpolate_occlusion(const float *d0, const float *outlier, float *out, int H, int W, void *stream);
+
+/* adcensus.interpolate_mismatch(d0, outlier) -> new tensor, adcensus.cu:1060-1077 (kernel 1001-1058). */
+int mc_interpolate_mismatch(const float *d0, const float *outlier, float *out, int H, int W, void *stream);
+
+/* adcensus.subpixel_enchancement(d0, c2, disp_max) -> new tensor, adcensus.cu:1222-1239
+ * (kernel 1205-1220).  vol: (D,H,W). */
+int mc_subpixel_enchancement(const float *d0, const float *vol, float *out, int D, int H, int W, void *stream);
+
+/* adcensus.median2d(img, kernel_size) -> new tensor, adcensus.cu:1596-1613 (kernel 1575-1594). k odd, <= 11. */
+int mc_median2d(const float *img, float *out, int H, int W, int kernel_size, void *stream);
+
+/* adcensus.mean2d(img, kernel, alpha2) -> new tensor, adcensus.cu:1263-1282 (kernel 1241-1261).
+ * kernel: (ks,ks) device array, ks odd. */
+int mc_mean2d(const float *img, const float *kernel, float *out, int H, int W, int ks, float alpha2, void *stream);
+
+/* gaussian(sigma), main.lua:528-540, computed on the host in double and
+ * rounded to float.  Returns ks = 2*ceil(3 sigma)+1; fills host_kernel
+ * (ks*ks floats) when it is non-NULL and capacity >= ks*ks. */
+int mc_gaussian_host(double sigma, float *host_kernel, int capacity);
+
+/* adcensus.Normalize_forward(input, norm, output), adcensus.cu:1310-1333
+ * (kernels 1284-1308).  x: (N,C,H,W); norm: (N,1,H,W). */
+int mc_normalize_forward(const float *in, float *norm, float *out, int N, int C, int H, int W, void *stream);
+
+/* ---- fused pipeline: stereo_predict, main.lua:929-1082 ------------------ */
+
+typedef struct mc_params {
+	int L1;            /* -L1        main.lua:87,132,222 ... */
+	float tau1;        /* -tau1 */
+	int cbca_i1;       /* -cbca_i1 */
+	int cbca_i2;       /* -cbca_i2 */
+	float pi1;         /* -pi1 */
+	float pi2;         /* -pi2 (passed to sgm2 as P2, main.lua:1015) */
+	int sgm_i;         /* -sgm_i */
+	float sgm_q1;      /* -sgm_q1 */
+	float sgm_q2;      /* -sgm_q2 */
+	float alpha1;      /* -alpha1 */
+	float tau_so;      /* -tau_so */
+	double blur_sigma; /* -blur_sigma (double: gaussian() runs in Lua doubles) */
+	float blur_t;      /* -blur_t */
+	int lr_check;      /* 1 = kitti/kitti2015 branch main.lua:1054-1066, 0 = mb */
+	int border_n;      /* fix_border n = (get_window_size(net)-1)/2, main.lua:923 */
+	int median_k;      /* 5, main.lua:1073 */
+} mc_params;
+
+/* Workspace bytes mc_predict needs for the given problem. */
+size_t mc_predict_workspace_bytes(const mc_params *p, int C, int D, int H, int W);
+
+/* stereo_predict(x_batch, id), main.lua:929-1082, from the cost-volume stage on.
+ *   x0,x1    (H,W) normalised left/right images (x_batch[1], x_batch[2]);
+ *   featL/R  (C,H,W) normalised features (arch fast: StereoJoin + fix_border,
+ *            main.lua:945-949), or NULL to start from
+ *   rawL/R   (D,H,W) raw left/right volumes (arch slow output of main.lua:958-983
+ *            / ad / census); NOT modified.
+ *   volL_out/volR_out  optional (D,H,W): what left.bin/right.bin hold (main.lua:1042-1047);
+ *   dispL0_out/dispR0_out optional (H,W): argmin maps before post-processing;
+ *   disp_out (H,W): the returned disparity (main.lua:1081).
+ * Runs asynchronously on `stream` inside `workspace`. */
+int mc_predict(const mc_params *p, const float *x0, const float *x1,
+               const float *featL, const float *featR, int C,
+               const float *rawL, const float *rawR, int D, int H, int W,
+               void *workspace, size_t workspace_bytes,
+               float *volL_out, float *volR_out, float *dispL0_out, float *dispR0_out,
+               float *disp_out, void *stream);
+
+/* Timing hook for bench.py: the same pipeline with HIP events recorded on `stream`
+ * at the stage boundaries of this call.  stage_ms[MC_N_STAGES] receives the summed
+ * duration (ms) of each stage; the call synchronises the stream to read them. */
+enum {
+	MC_STAGE_PREP = 0,   /* SGM edge-class maps + cross arms */
+	MC_STAGE_JOIN = 1,   /* StereoJoin (+ NaN fill, fix_border) */
+	MC_STAGE_CBCA = 2,   /* all cbca iterations */
+	MC_STAGE_LAYOUT = 3, /* (D,H,W) <-> (H,W,D) transposes */
+	MC_STAGE_SGM = 4,    /* the four direction sweeps, nothing else */
+	MC_STAGE_ARGMIN = 5, /* stand-alone argmin + optional volume export */
+	MC_STAGE_POST = 6,   /* LR check .. range-gated Gaussian */
+	MC_N_STAGES = 8
+};
+int mc_predict_timed(const mc_params *p, const float *x0, const float *x1,
+                     const float *featL, const float *featR, int C,
+                     const float *rawL, const float *rawR, int D, int H, int W,
+                     void *workspace, size_t workspace_bytes, float *disp_out, void *stream,
+                     float *stage_ms);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_ADCENSUS_H */

@@ -1,0 +1,538 @@
+// extern "C" surface of libmcadcensus.so (see include/mc_adcensus.h) and the fused
+// stereo_predict pipeline (main.lua:929-1082).
+#include "mc_common.h"
+
+#include <stdarg.h>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace mc {
+
+// kernels.hip units
+int fill_nan(float *p, int64_t n, hipStream_t st);
+int scale(const float *in, float *out, int64_t n, float s, hipStream_t st);
+int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, int64_t ldout, float s, hipStream_t st);
+int fix_border(float *vol, int D, int H, int W, int n, int direction, hipStream_t st);
+int argmin_dhw(const float *vol, float *out, int D, int H, int W, int base1, hipStream_t st);
+int argmin_hwd(const float *vol, float *out, int D, int ds, int H, int W, hipStream_t st);
+int outlier_detection(const float *d0, const float *d1, float *outlier, int H, int W, int disp_max, hipStream_t st);
+int interpolate_occlusion(const float *d0, const float *outlier, float *out, int H, int W, hipStream_t st);
+int interpolate_mismatch(const float *d0, const float *outlier, float *out, int H, int W, hipStream_t st);
+int subpixel(const float *d0, const float *vol, float *out, int D, int H, int W, int64_t sd, int64_t sp, hipStream_t st);
+int median2d(const float *img, float *out, int H, int W, int k, hipStream_t st);
+int mean2d(const float *img, const float *kernel, float *out, int H, int W, int ks, float alpha2, hipStream_t st);
+int normalize_forward(const float *in, float *norm, float *out, int N, int C, int H, int W, hipStream_t st);
+int stereo_join_dhw(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int H, int W, hipStream_t st);
+int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int ds, int H, int W, int n,
+                    hipStream_t st);
+int ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, hipStream_t st);
+int census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, hipStream_t st);
+int cross(const float *img, float *arms, int H, int W, int L1, float tau1, hipStream_t st);
+int cbca(const float *x0c, const float *x1c, const float *vin, float *vout, int D, int H, int W, int direction, hipStream_t st);
+size_t sgm_maps_bytes(int H, int W);
+int sgm_prep(const float *x0, const float *x1, void *maps, int H, int W, float tau_so, hipStream_t st);
+int sgm_sweeps(const float *const C[2], float *const out[2], float *const disp[2], const int direction[2], int nvol, int H,
+               int W, int D, int ds, const void *maps, float pi1, float pi2, float alpha1, float q1, float q2, bool fused,
+               hipStream_t st);
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+int check_launch(const char *what)
+{
+	const hipError_t e = hipPeekAtLastError();
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		set_error("%s: %s", what, hipGetErrorString(e));
+		return (int)e;
+	}
+	return 0;
+}
+
+static bool dims_ok(int D, int H, int W) { return D >= 1 && H >= 1 && W >= 1 && (int64_t)D * H * W < ((int64_t)1 << 40); }
+
+// gaussian(sigma), main.lua:528-540, double on the host.  Cached per sigma; vectors are never
+// freed so that an in-flight async upload never sees its source disappear.
+static const std::vector<float> &gaussian_cached(double sigma)
+{
+	static std::mutex mu;
+	static std::map<double, std::vector<float> *> cache;
+	std::lock_guard<std::mutex> lk(mu);
+	auto it = cache.find(sigma);
+	if (it != cache.end()) return *it->second;
+	const int kr = (int)ceil(sigma * 3);
+	const int ks = kr * 2 + 1;
+	auto *k = new std::vector<float>((size_t)ks * ks);
+	for (int i = 1; i <= ks; ++i) {
+		for (int j = 1; j <= ks; ++j) {
+			const double y = (i - 1) - kr;
+			const double x = (j - 1) - kr;
+			(*k)[(size_t)(i - 1) * ks + (j - 1)] = (float)exp(-(x * x + y * y) / (2 * sigma * sigma));
+		}
+	}
+	cache[sigma] = k;
+	return *k;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Plan {
+	int Dp;                 // padded pixel stride of the (H,W,Dp) volumes
+	size_t maps, arms, vol, img, gk;
+	size_t total;
+};
+
+static Plan make_plan(const mc_params *p, int D, int H, int W)
+{
+	Plan pl;
+	pl.Dp = (D + 3) / 4 * 4;
+	const size_t HW = (size_t)H * W;
+	pl.maps = align_up(sgm_maps_bytes(H, W), 256);
+	pl.arms = align_up(8 * HW * sizeof(float), 256);
+	pl.vol = align_up((size_t)pl.Dp * HW * sizeof(float), 256);
+	pl.img = align_up(HW * sizeof(float), 256);
+	const int kr = (int)ceil(p->blur_sigma * 3);
+	const int ks = 2 * kr + 1;
+	pl.gk = align_up((size_t)ks * ks * sizeof(float), 256);
+	pl.total = pl.maps + pl.arms + 4 * pl.vol + 6 * pl.img + pl.gk;
+	return pl;
+}
+
+struct StageTimer {
+	bool on = false;
+	hipStream_t st;
+	std::vector<hipEvent_t> ev;
+	std::vector<int> tag;  // stage id the interval ENDING at this event belongs to
+	void mark(int stage)
+	{
+		if (!on) return;
+		hipEvent_t e;
+		(void)hipEventCreate(&e);
+		(void)hipEventRecord(e, st);
+		ev.push_back(e);
+		tag.push_back(stage);
+	}
+	void collect(float out[MC_N_STAGES])
+	{
+		for (int i = 0; i < MC_N_STAGES; ++i) out[i] = 0;
+		if (!on || ev.empty()) return;
+		(void)hipEventSynchronize(ev.back());
+		for (size_t i = 1; i < ev.size(); ++i) {
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+			if (tag[i] >= 0 && tag[i] < MC_N_STAGES) out[tag[i]] += ms;
+		}
+		for (auto e : ev) (void)hipEventDestroy(e);
+		ev.clear();
+	}
+};
+enum { ST_PREP = MC_STAGE_PREP, ST_JOIN = MC_STAGE_JOIN, ST_CBCA = MC_STAGE_CBCA, ST_LAYOUT = MC_STAGE_LAYOUT,
+       ST_SGM = MC_STAGE_SGM, ST_ARGMIN = MC_STAGE_ARGMIN, ST_POST = MC_STAGE_POST };
+
+static int predict_impl(const mc_params *p, const float *x0, const float *x1, const float *featL, const float *featR, int C,
+                        const float *rawL, const float *rawR, int D, int H, int W, void *workspace, size_t workspace_bytes,
+                        float *volL_out, float *volR_out, float *dispL0_out, float *dispR0_out, float *disp_out, hipStream_t st,
+                        StageTimer &tm)
+{
+	MC_REQUIRE(p && x0 && x1 && disp_out && workspace, "mc_predict: null argument");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_predict: bad dims D=%d H=%d W=%d", D, H, W);
+	MC_REQUIRE(D <= MC_SGM_MAX_D, "mc_predict: D=%d exceeds %d", D, MC_SGM_MAX_D);
+	MC_REQUIRE((featL && featR && C >= 1) || (rawL && rawR), "mc_predict: need features or raw volumes");
+	MC_REQUIRE(p->cbca_i1 >= 0 && p->cbca_i2 >= 0 && p->sgm_i >= 0, "mc_predict: negative iteration count");
+	MC_REQUIRE(p->median_k % 2 == 1 && p->median_k <= 11, "mc_predict: median_k must be odd and <= 11");
+	MC_REQUIRE(p->blur_sigma > 0, "mc_predict: blur_sigma must be > 0");
+	const bool from_feat = featL != nullptr;
+	if (from_feat) MC_REQUIRE(p->border_n >= 0 && p->border_n < W, "mc_predict: border_n=%d out of range", p->border_n);
+	const Plan pl = make_plan(p, D, H, W);
+	MC_REQUIRE(workspace_bytes >= pl.total, "mc_predict: workspace %zu < %zu bytes", workspace_bytes, pl.total);
+	MC_REQUIRE((uintptr_t)workspace % 256 == 0, "mc_predict: workspace must be 256-byte aligned");
+
+	const int64_t HW = (int64_t)H * W;
+	const int64_t V = (int64_t)D * HW;
+	char *w = (char *)workspace;
+	void *maps = w; w += pl.maps;
+	float *x0c = (float *)w; float *x1c = x0c + 4 * HW; w += pl.arms;
+	float *bufA[2], *bufB[2];
+	bufA[0] = (float *)w; w += pl.vol;
+	bufA[1] = (float *)w; w += pl.vol;
+	bufB[0] = (float *)w; w += pl.vol;
+	bufB[1] = (float *)w; w += pl.vol;
+	float *img[6];
+	for (int i = 0; i < 6; ++i) { img[i] = (float *)w; w += pl.img; }
+	float *gk = (float *)w;
+	const int Dp = pl.Dp;
+	int rc;
+#define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
+
+	// index 0 = left volume (direction -1), 1 = right volume (direction +1)  (main.lua:986)
+	const int direction[2] = {-1, 1};
+	const bool use_cbca = (p->cbca_i1 + p->cbca_i2) > 0;
+	tm.mark(-1);
+
+	if (p->sgm_i > 0) RUN(sgm_prep(x0, x1, maps, H, W, p->tau_so, st));
+	if (use_cbca) {  // main.lua:993-996: x0c from the LEFT image, x1c from the RIGHT, for both directions
+		RUN(cross(x0, x0c, H, W, p->L1, p->tau1, st));
+		RUN(cross(x1, x1c, H, W, p->L1, p->tau1, st));
+	}
+	tm.mark(ST_PREP);
+
+	// ---- (A) cost volumes + CBCA-1; ends with cur[v] and its layout ----
+	// Internal (H,W,ds) volumes use the padded pixel stride ds = Dp (multiple of 4) so that
+	// every lane's run of 4 disparities is one aligned 16-byte access.
+	const int ds = Dp;
+	const float *cur[2];
+	auto other = [&](int v) -> float * { return cur[v] == bufA[v] ? bufB[v] : bufA[v]; };
+	bool hwd;  // layout of cur[]
+	if (from_feat && p->cbca_i1 == 0 && p->sgm_i > 0) {
+		// fast path: StereoJoin straight into (H,W,ds) with NaN fill and fix_border folded in
+		RUN(stereo_join_hwd(featL, featR, bufA[0], bufA[1], C, D, ds, H, W, p->border_n, st));
+		cur[0] = bufA[0]; cur[1] = bufA[1];
+		hwd = true;
+		tm.mark(ST_JOIN);
+	} else {
+		if (from_feat) {  // main.lua:946-949
+			RUN(fill_nan(bufA[0], V, st));
+			RUN(fill_nan(bufA[1], V, st));
+			RUN(stereo_join_dhw(featL, featR, bufA[0], bufA[1], C, D, H, W, st));
+			RUN(fix_border(bufA[0], D, H, W, p->border_n, -1, st));
+			RUN(fix_border(bufA[1], D, H, W, p->border_n, 1, st));
+			cur[0] = bufA[0]; cur[1] = bufA[1];
+		} else {
+			cur[0] = rawL; cur[1] = rawR;
+		}
+		hwd = false;
+		tm.mark(ST_JOIN);
+		for (int i = 0; i < p->cbca_i1; ++i) {  // main.lua:998-1001 (ping-pong instead of vol:copy(tmp))
+			for (int v = 0; v < 2; ++v) {
+				float *dst = other(v);
+				RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));
+				cur[v] = dst;
+			}
+		}
+		tm.mark(ST_CBCA);
+	}
+
+	// ---- (B) SGM, main.lua:1007-1030 ----
+	float *dispv[2] = {img[0], img[1]};  // [0] = left disparity (disp[2] in Lua), [1] = right
+	bool have_disp = false;
+	if (p->sgm_i > 0) {
+		if (!hwd) {  // vol:transpose(2,3):transpose(3,4):clone(), main.lua:1008
+			for (int v = 0; v < 2; ++v) {
+				float *dst = other(v);
+				RUN(transpose(cur[v], dst, D, HW, HW, ds, 1.0f, st));
+				cur[v] = dst;
+			}
+			hwd = true;
+			tm.mark(ST_LAYOUT);
+		}
+		for (int it = 0; it < p->sgm_i; ++it) {
+			// out:zero(); sgm2(...); vol:copy(out):div(4)  (main.lua:1013-1018): the zero is folded
+			// into the first sweep (0 + L_0) and the /4 into the last
+			const float *Cv[2] = {cur[0], cur[1]};
+			float *outv[2] = {other(0), other(1)};
+			const bool am = (it == p->sgm_i - 1) && p->cbca_i2 == 0;
+			RUN(sgm_sweeps(Cv, outv, am ? dispv : nullptr, direction, 2, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
+			               p->sgm_q1, p->sgm_q2, true, st));
+			have_disp = am;
+			cur[0] = outv[0]; cur[1] = outv[1];
+		}
+		tm.mark(ST_SGM);
+		if (p->cbca_i2 > 0) {  // back to (D,H,W): vol:copy(out:transpose(3,4):transpose(2,3)), main.lua:1019-1020
+			for (int v = 0; v < 2; ++v) {
+				float *dst = other(v);
+				RUN(transpose(cur[v], dst, HW, D, ds, HW, 1.0f, st));
+				cur[v] = dst;
+			}
+			hwd = false;
+			tm.mark(ST_LAYOUT);
+		}
+	}
+	if (!hwd) {  // CBCA-2, main.lua:1033-1039
+		for (int i = 0; i < p->cbca_i2; ++i) {
+			for (int v = 0; v < 2; ++v) {
+				float *dst = other(v);
+				RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));
+				cur[v] = dst;
+			}
+		}
+		tm.mark(ST_CBCA);
+	}
+
+	// ---- argmin, main.lua:1049-1050 ----
+	if (!have_disp) {
+		for (int v = 0; v < 2; ++v) {
+			if (hwd) RUN(argmin_hwd(cur[v], dispv[v], D, ds, H, W, st));
+			else RUN(argmin_dhw(cur[v], dispv[v], D, H, W, 0, st));
+		}
+	}
+	// ---- left.bin / right.bin contents, main.lua:1042-1047 ----
+	float *vout[2] = {volL_out, volR_out};
+	for (int v = 0; v < 2; ++v) {
+		if (!vout[v]) continue;
+		if (hwd) RUN(transpose(cur[v], vout[v], HW, D, ds, HW, 1.0f, st));
+		else RUN(scale(cur[v], vout[v], V, 1.0f, st));
+	}
+	if (dispL0_out) RUN(scale(dispv[0], dispL0_out, HW, 1.0f, st));
+	if (dispR0_out) RUN(scale(dispv[1], dispR0_out, HW, 1.0f, st));
+	tm.mark(ST_ARGMIN);
+
+	// ---- (C) post-processing on the LEFT disparity, main.lua:1054-1081 ----
+	float *d = dispv[0];
+	float *t = img[2];
+	float *t2 = img[3];
+	float *outl = img[4];
+	if (p->lr_check) {
+		RUN(outlier_detection(d, dispv[1], outl, H, W, D, st));
+		RUN(interpolate_occlusion(d, outl, t, H, W, st));
+		RUN(interpolate_mismatch(t, outl, t2, H, W, st));
+		d = t2;
+		t2 = img[5];
+	}
+	// subpixel on the LEFT volume (vol of the last loop iteration, main.lua:1068)
+	if (hwd) RUN(subpixel(d, cur[0], t, D, H, W, 1, ds, st));
+	else RUN(subpixel(d, cur[0], t, D, H, W, HW, 1, st));
+	RUN(median2d(t, t2, H, W, p->median_k, st));
+	{
+		const std::vector<float> &k = gaussian_cached(p->blur_sigma);
+		const int ks = 2 * (int)ceil(p->blur_sigma * 3) + 1;
+		const hipError_t e = hipMemcpyAsync(gk, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice, st);
+		if (e != hipSuccess) {
+			set_error("mc_predict: kernel upload: %s", hipGetErrorString(e));
+			return (int)e;
+		}
+		RUN(mean2d(t2, gk, disp_out, H, W, ks, p->blur_t, st));
+	}
+	tm.mark(ST_POST);
+#undef RUN
+	return 0;
+}
+
+}  // namespace mc
+
+using namespace mc;
+
+extern "C" {
+
+int mc_version(void) { return MC_ABI_VERSION; }
+const char *mc_last_error(void) { return g_err; }
+
+int mc_fill_nan(float *p, int64_t n, void *stream)
+{
+	MC_REQUIRE(p || n == 0, "mc_fill_nan: null pointer");
+	MC_REQUIRE(n >= 0, "mc_fill_nan: negative size");
+	return fill_nan(p, n, as_stream(stream));
+}
+
+int mc_stereo_join(const float *featL, const float *featR, float *volL, float *volR, int C, int D, int H, int W, void *stream)
+{
+	MC_REQUIRE(featL && featR && volL && volR, "mc_stereo_join: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W) && C >= 1, "mc_stereo_join: bad dims C=%d D=%d H=%d W=%d", C, D, H, W);
+	MC_REQUIRE(C <= MC_JOIN_MAX_C, "mc_stereo_join: C=%d exceeds %d (adcensus.cu:1460)", C, MC_JOIN_MAX_C);
+	MC_REQUIRE(D <= 65535, "mc_stereo_join: D too large");
+	return stereo_join_dhw(featL, featR, volL, volR, C, D, H, W, as_stream(stream));
+}
+
+int mc_ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, void *stream)
+{
+	MC_REQUIRE(x0 && x1 && vol, "mc_ad: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_ad: bad dims");
+	MC_REQUIRE(direction == -1 || direction == 1, "mc_ad: direction must be -1 or 1");
+	return ad(x0, x1, vol, D, H, W, direction, as_stream(stream));
+}
+
+int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, void *stream)
+{
+	MC_REQUIRE(x0 && x1 && vol, "mc_census: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W) && Cimg >= 1, "mc_census: bad dims");
+	MC_REQUIRE(direction == -1 || direction == 1, "mc_census: direction must be -1 or 1");
+	return census(x0, x1, vol, Cimg, D, H, W, direction, as_stream(stream));
+}
+
+int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream)
+{
+	MC_REQUIRE(vol, "mc_fix_border: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_fix_border: bad dims");
+	MC_REQUIRE(n >= 0 && n < W, "mc_fix_border: n=%d out of range for W=%d", n, W);
+	MC_REQUIRE(direction == -1 || direction == 1, "mc_fix_border: direction must be -1 or 1");
+	return fix_border(vol, D, H, W, n, direction, as_stream(stream));
+}
+
+int mc_cross(const float *img, float *arms, int H, int W, int L1, float tau1, void *stream)
+{
+	MC_REQUIRE(img && arms, "mc_cross: null pointer");
+	MC_REQUIRE(dims_ok(1, H, W), "mc_cross: bad dims");
+	return cross(img, arms, H, W, L1, tau1, as_stream(stream));
+}
+
+int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
+            void *stream)
+{
+	MC_REQUIRE(x0c && x1c && vol_in && vol_out, "mc_cbca: null pointer");
+	MC_REQUIRE(vol_in != vol_out, "mc_cbca: in-place aggregation is not supported (the reference uses a tmp volume too)");
+	MC_REQUIRE(dims_ok(D, H, W) && D <= 65535, "mc_cbca: bad dims");
+	MC_REQUIRE(direction == -1 || direction == 1, "mc_cbca: direction must be -1 or 1");
+	return cbca(x0c, x1c, vol_in, vol_out, D, H, W, direction, as_stream(stream));
+}
+
+size_t mc_sgm2_tmp_bytes(int H, int W, int D)
+{
+	(void)D;
+	if (H < 1 || W < 1) return 0;
+	return sgm_maps_bytes(H, W);
+}
+
+int mc_sgm2(const float *x0, const float *x1, const float *in_hwd, float *out_hwd, void *tmp, size_t tmp_bytes, int H, int W,
+            int D, float pi1, float pi2, float tau_so, float alpha1, float sgm_q1, float sgm_q2, int direction, void *stream)
+{
+	MC_REQUIRE(x0 && x1 && in_hwd && out_hwd && tmp, "mc_sgm2: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_sgm2: bad dims");
+	MC_REQUIRE(D <= MC_SGM_MAX_D, "mc_sgm2: D=%d exceeds %d", D, MC_SGM_MAX_D);
+	MC_REQUIRE(direction == -1 || direction == 1, "mc_sgm2: direction must be -1 or 1");
+	MC_REQUIRE(tmp_bytes >= sgm_maps_bytes(H, W), "mc_sgm2: tmp holds %zu bytes, needs %zu", tmp_bytes, sgm_maps_bytes(H, W));
+	MC_REQUIRE(in_hwd != out_hwd, "mc_sgm2: input and output must differ");
+	hipStream_t st = as_stream(stream);
+	int rc = sgm_prep(x0, x1, tmp, H, W, tau_so, st);
+	if (rc) return rc;
+	const float *Cv[2] = {in_hwd, in_hwd};
+	float *outv[2] = {out_hwd, out_hwd};
+	const int dirv[2] = {direction, direction};
+	return sgm_sweeps(Cv, outv, nullptr, dirv, 1, H, W, D, D, tmp, pi1, pi2, alpha1, sgm_q1, sgm_q2, false, st);
+}
+
+int mc_dhw_to_hwd(const float *in, float *out, int D, int H, int W, void *stream)
+{
+	MC_REQUIRE(in && out && in != out, "mc_dhw_to_hwd: bad pointers");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_dhw_to_hwd: bad dims");
+	return transpose(in, out, D, (int64_t)H * W, (int64_t)H * W, D, 1.0f, as_stream(stream));
+}
+
+int mc_hwd_to_dhw(const float *in, float *out, int D, int H, int W, float scale_, void *stream)
+{
+	MC_REQUIRE(in && out && in != out, "mc_hwd_to_dhw: bad pointers");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_hwd_to_dhw: bad dims");
+	return transpose(in, out, (int64_t)H * W, D, D, (int64_t)H * W, scale_, as_stream(stream));
+}
+
+int mc_scale(const float *in, float *out, int64_t n, float s, void *stream)
+{
+	MC_REQUIRE((in && out) || n == 0, "mc_scale: null pointer");
+	MC_REQUIRE(n >= 0, "mc_scale: negative size");
+	return scale(in, out, n, s, as_stream(stream));
+}
+
+int mc_argmin(const float *vol, float *disp, int D, int H, int W, void *stream)
+{
+	MC_REQUIRE(vol && disp, "mc_argmin: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_argmin: bad dims");
+	return argmin_dhw(vol, disp, D, H, W, 0, as_stream(stream));
+}
+
+int mc_spatial_argmin(const float *vol, float *out, int D, int H, int W, void *stream)
+{
+	MC_REQUIRE(vol && out, "mc_spatial_argmin: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_spatial_argmin: bad dims");
+	return argmin_dhw(vol, out, D, H, W, 1, as_stream(stream));
+}
+
+int mc_outlier_detection(const float *d0, const float *d1, float *outlier, int H, int W, int disp_max, void *stream)
+{
+	MC_REQUIRE(d0 && d1 && outlier, "mc_outlier_detection: null pointer");
+	MC_REQUIRE(dims_ok(1, H, W) && disp_max >= 0, "mc_outlier_detection: bad dims");
+	return outlier_detection(d0, d1, outlier, H, W, disp_max, as_stream(stream));
+}
+
+int mc_interpolate_occlusion(const float *d0, const float *outlier, float *out, int H, int W, void *stream)
+{
+	MC_REQUIRE(d0 && outlier && out && out != d0, "mc_interpolate_occlusion: bad pointers");
+	MC_REQUIRE(dims_ok(1, H, W), "mc_interpolate_occlusion: bad dims");
+	return interpolate_occlusion(d0, outlier, out, H, W, as_stream(stream));
+}
+
+int mc_interpolate_mismatch(const float *d0, const float *outlier, float *out, int H, int W, void *stream)
+{
+	MC_REQUIRE(d0 && outlier && out && out != d0, "mc_interpolate_mismatch: bad pointers");
+	MC_REQUIRE(dims_ok(1, H, W), "mc_interpolate_mismatch: bad dims");
+	return interpolate_mismatch(d0, outlier, out, H, W, as_stream(stream));
+}
+
+int mc_subpixel_enchancement(const float *d0, const float *vol, float *out, int D, int H, int W, void *stream)
+{
+	MC_REQUIRE(d0 && vol && out, "mc_subpixel_enchancement: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_subpixel_enchancement: bad dims");
+	return subpixel(d0, vol, out, D, H, W, (int64_t)H * W, 1, as_stream(stream));
+}
+
+int mc_median2d(const float *img, float *out, int H, int W, int kernel_size, void *stream)
+{
+	MC_REQUIRE(img && out && img != out, "mc_median2d: bad pointers");
+	MC_REQUIRE(dims_ok(1, H, W), "mc_median2d: bad dims");
+	MC_REQUIRE(kernel_size % 2 == 1 && kernel_size >= 1 && kernel_size <= 11,
+	           "mc_median2d: kernel_size must be odd and <= 11 (adcensus.cu:1601-1602)");
+	return median2d(img, out, H, W, kernel_size, as_stream(stream));
+}
+
+int mc_mean2d(const float *img, const float *kernel, float *out, int H, int W, int ks, float alpha2, void *stream)
+{
+	MC_REQUIRE(img && kernel && out && img != out, "mc_mean2d: bad pointers");
+	MC_REQUIRE(dims_ok(1, H, W), "mc_mean2d: bad dims");
+	MC_REQUIRE(ks % 2 == 1 && ks >= 1, "mc_mean2d: kernel size must be odd (adcensus.cu:1269)");
+	return mean2d(img, kernel, out, H, W, ks, alpha2, as_stream(stream));
+}
+
+int mc_gaussian_host(double sigma, float *host_kernel, int capacity)
+{
+	MC_REQUIRE(sigma > 0, "mc_gaussian_host: sigma must be > 0");
+	const std::vector<float> &k = gaussian_cached(sigma);
+	const int ks = 2 * (int)ceil(sigma * 3) + 1;
+	if (host_kernel) {
+		MC_REQUIRE(capacity >= ks * ks, "mc_gaussian_host: capacity %d < %d", capacity, ks * ks);
+		for (size_t i = 0; i < k.size(); ++i) host_kernel[i] = k[i];
+	}
+	return ks;
+}
+
+int mc_normalize_forward(const float *in, float *norm, float *out, int N, int C, int H, int W, void *stream)
+{
+	MC_REQUIRE(in && out, "mc_normalize_forward: null pointer");
+	MC_REQUIRE(N >= 1 && C >= 1 && dims_ok(1, H, W), "mc_normalize_forward: bad dims");
+	return normalize_forward(in, norm, out, N, C, H, W, as_stream(stream));
+}
+
+size_t mc_predict_workspace_bytes(const mc_params *p, int C, int D, int H, int W)
+{
+	(void)C;
+	if (!p || !dims_ok(D, H, W) || !(p->blur_sigma > 0)) return 0;
+	return make_plan(p, D, H, W).total;
+}
+
+int mc_predict(const mc_params *p, const float *x0, const float *x1, const float *featL, const float *featR, int C,
+               const float *rawL, const float *rawR, int D, int H, int W, void *workspace, size_t workspace_bytes,
+               float *volL_out, float *volR_out, float *dispL0_out, float *dispR0_out, float *disp_out, void *stream)
+{
+	StageTimer tm;
+	return predict_impl(p, x0, x1, featL, featR, C, rawL, rawR, D, H, W, workspace, workspace_bytes, volL_out, volR_out,
+	                    dispL0_out, dispR0_out, disp_out, as_stream(stream), tm);
+}
+
+int mc_predict_timed(const mc_params *p, const float *x0, const float *x1, const float *featL, const float *featR, int C,
+                     const float *rawL, const float *rawR, int D, int H, int W, void *workspace, size_t workspace_bytes,
+                     float *disp_out, void *stream, float *stage_ms)
+{
+	StageTimer tm;
+	tm.on = stage_ms != nullptr;
+	tm.st = as_stream(stream);
+	const int rc = predict_impl(p, x0, x1, featL, featR, C, rawL, rawR, D, H, W, workspace, workspace_bytes, nullptr, nullptr,
+	                            nullptr, nullptr, disp_out, tm.st, tm);
+	if (stage_ms) tm.collect(stage_ms);
+	return rc;
+}
+
+}  // extern "C"

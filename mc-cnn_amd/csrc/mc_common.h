@@ -1,0 +1,61 @@
+// Shared helpers for the gfx950 kernels of libmcadcensus.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/mc_adcensus.h"
+
+namespace mc {
+
+// ---- error reporting (mc_last_error) ---------------------------------------
+void set_error(const char *fmt, ...);
+int check_launch(const char *what);  // hipPeekAtLastError -> rc, like checkCudaError (adcensus.cu:31-36)
+
+#define MC_REQUIRE(cond, ...)                 \
+	do {                                      \
+		if (!(cond)) {                        \
+			mc::set_error(__VA_ARGS__);       \
+			return MC_EINVAL;                 \
+		}                                     \
+	} while (0)
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ---- wave64 cross-lane primitives (DPP, no LDS round trip) -------------------
+// gfx9 DPP controls.
+constexpr int DPP_QUAD_1032 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_2301 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_BCAST15 = 0x142;
+constexpr int DPP_ROW_BCAST31 = 0x143;
+constexpr int DPP_WAVE_SHL1 = 0x130;       // lane i <- lane i+1
+constexpr int DPP_WAVE_SHR1 = 0x138;       // lane i <- lane i-1
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_mov(float old, float src)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL,
+	                                                  ROW_MASK, 0xF, false));
+}
+
+// min over the 64 lanes, NaN-ignoring (fminf), returned wave-uniform.
+__device__ __forceinline__ float wave_min(float v)
+{
+	v = fminf(v, dpp_mov<DPP_QUAD_1032>(v, v));
+	v = fminf(v, dpp_mov<DPP_QUAD_2301>(v, v));
+	v = fminf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v, v));
+	v = fminf(v, dpp_mov<DPP_ROW_MIRROR>(v, v));
+	v = fminf(v, dpp_mov<DPP_ROW_BCAST15, 0xA>(v, v));
+	v = fminf(v, dpp_mov<DPP_ROW_BCAST31, 0xC>(v, v));
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// value of lane-1 (lane 0 gets `fill`) / lane+1 (lane 63 gets `fill`)
+__device__ __forceinline__ float lane_from_below(float v, float fill) { return dpp_mov<DPP_WAVE_SHR1>(fill, v); }
+__device__ __forceinline__ float lane_from_above(float v, float fill) { return dpp_mov<DPP_WAVE_SHL1>(fill, v); }
+
+}  // namespace mc

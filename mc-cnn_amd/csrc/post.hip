@@ -1,0 +1,439 @@
+// H*W-sized disparity kernels and layout helpers (gfx950).
+// Each kernel cites the adcensus.cu kernel whose arithmetic it reproduces.
+#include "mc_common.h"
+
+namespace mc {
+
+// ---- fill / scale / transposes ---------------------------------------------------
+
+__global__ void __launch_bounds__(256) fill_nan_kernel(float *__restrict__ p, int64_t n)
+{
+	const float nanv = __builtin_nanf("");
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = nanv;
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t n, float s)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[i] * s;
+}
+
+// out[c*ldout + r] = in[r*ldin + c] * s for an R x Cn matrix, 64x64 tiles through LDS.
+// (D,H,W)->(H,W,ds) is R=D, Cn=H*W, ldin=H*W, ldout=ds; the inverse is R=H*W, Cn=D, ldin=ds, ldout=H*W.
+__global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t R,
+                                                        int64_t Cn, int64_t ldin, int64_t ldout, float s)
+{
+	__shared__ float tile[64][65];
+	const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	for (int k = ty; k < 64; k += 4) {
+		const int64_t r = r0 + k, c = c0 + tx;
+		if (r < R && c < Cn) tile[k][tx] = in[r * ldin + c];
+	}
+	__syncthreads();
+	for (int k = ty; k < 64; k += 4) {
+		const int64_t c = c0 + k, r = r0 + tx;
+		if (r < R && c < Cn) out[c * ldout + r] = tile[tx][k] * s;
+	}
+}
+
+int fill_nan(float *p, int64_t n, hipStream_t st)
+{
+	if (n <= 0) return 0;
+	const unsigned blocks = cdiv(n, 256) < 4096u ? cdiv(n, 256) : 4096u;
+	hipLaunchKernelGGL(fill_nan_kernel, dim3(blocks), dim3(256), 0, st, p, n);
+	return check_launch("fill_nan");
+}
+
+int scale(const float *in, float *out, int64_t n, float s, hipStream_t st)
+{
+	if (n <= 0) return 0;
+	const unsigned blocks = cdiv(n, 256) < 4096u ? cdiv(n, 256) : 4096u;
+	hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, st, in, out, n, s);
+	return check_launch("scale");
+}
+
+int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, int64_t ldout, float s, hipStream_t st)
+{
+	// the long axis goes to grid.x (grid.y is limited to 65535 blocks)
+	hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+	return check_launch("transpose");
+}
+
+// ---- fix_border (main.lua:922-927) ---------------------------------------------------
+// (D,H,W): vol[.., dst] = vol[.., src] for the n outermost columns on one side.
+__global__ void __launch_bounds__(256) fix_border_kernel(float *__restrict__ vol, int64_t rows, int W, int n, int direction)
+{
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= rows * n) return;
+	const int i = (int)(id % n) + 1;
+	const int64_t r = id / n;
+	const int dst = direction < 0 ? W - i : i - 1;
+	const int src = direction < 0 ? W - (n + 1) : n;
+	vol[r * W + dst] = vol[r * W + src];
+}
+
+int fix_border(float *vol, int D, int H, int W, int n, int direction, hipStream_t st)
+{
+	if (n <= 0) return 0;
+	const int64_t rows = (int64_t)D * H;
+	hipLaunchKernelGGL(fix_border_kernel, dim3(cdiv(rows * n, 256)), dim3(256), 0, st, vol, rows, W, n, direction);
+	return check_launch("fix_border");
+}
+
+// ---- argmin -------------------------------------------------------------------------------
+// torch.min(vol,2)-1 (main.lua:1049-1050) with the spatial_argmin convention (adcensus.cu:244-262).
+// (D,H,W): one thread per pixel, coalesced along x.  base1 = 1 gives spatial_argmin's 1-based output.
+__global__ void __launch_bounds__(256) argmin_dhw_kernel(const float *__restrict__ vol, float *__restrict__ out, int D, int64_t HW,
+                                                         int base1)
+{
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= HW) return;
+	int argmin = 0;
+	float mn = __builtin_inff();
+	for (int i = 0; i < D; ++i) {
+		const float val = vol[i * HW + p];
+		if (val < mn) {
+			mn = val;
+			argmin = i;
+		}
+	}
+	out[p] = (float)(argmin + base1);
+}
+
+// (H,W,ds) layout: one wave per pixel, lanes over d.
+__global__ void __launch_bounds__(256) argmin_hwd_kernel(const float *__restrict__ vol, float *__restrict__ out, int D, int ds,
+                                                         int64_t HW)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (p >= HW) return;
+	const float INF = __builtin_inff();
+	float best = INF;
+	int bi = 0;
+	for (int d = lane; d < D; d += 64) {  // ascending d per lane keeps "first" semantics
+		const float val = vol[p * ds + d];
+		if (val < best) {
+			best = val;
+			bi = d;
+		}
+	}
+	const float mall = wave_min(best);
+	// smallest index among lanes holding the minimum
+	int cand = (best == mall && best < INF) ? bi : 0x7fffffff;
+	for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+	if (lane == 0) out[p] = (float)(cand == 0x7fffffff ? 0 : cand);
+}
+
+int argmin_dhw(const float *vol, float *out, int D, int H, int W, int base1, hipStream_t st)
+{
+	const int64_t HW = (int64_t)H * W;
+	hipLaunchKernelGGL(argmin_dhw_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, vol, out, D, HW, base1);
+	return check_launch("argmin_dhw");
+}
+
+int argmin_hwd(const float *vol, float *out, int D, int ds, int H, int W, hipStream_t st)
+{
+	const int64_t HW = (int64_t)H * W;
+	hipLaunchKernelGGL(argmin_hwd_kernel, dim3(cdiv(HW * 64, 256)), dim3(256), 0, st, vol, out, D, ds, HW);
+	return check_launch("argmin_hwd");
+}
+
+// ---- outlier_detection, adcensus.cu:878-899 ------------------------------------------------
+__global__ void __launch_bounds__(256) outlier_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
+                                                      float *__restrict__ outlier, int64_t size, int W, int disp_max)
+{
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= size) return;
+	const int x = (int)(id % W);
+	const int d0i = (int)d0[id];
+	float res;
+	if (x - d0i < 0) {
+		res = 1;
+	} else if ((double)fabsf(d0[id] - d1[id - d0i]) < 1.1) {
+		res = 0;
+	} else {
+		res = 1;
+		for (int d = 0; d < disp_max; ++d) {
+			if (x - d >= 0 && (double)fabsf((float)d - d1[id - d]) < 1.1) {
+				res = 2;
+				break;
+			}
+		}
+	}
+	outlier[id] = res;
+}
+
+int outlier_detection(const float *d0, const float *d1, float *outlier, int H, int W, int disp_max, hipStream_t st)
+{
+	const int64_t size = (int64_t)H * W;
+	hipLaunchKernelGGL(outlier_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, d0, d1, outlier, size, W, disp_max);
+	return check_launch("outlier_detection");
+}
+
+// ---- interpolate_occlusion, adcensus.cu:1079-1105 --------------------------------------------
+__global__ void __launch_bounds__(256) interp_occ_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
+                                                         float *__restrict__ out, int64_t size, int W)
+{
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= size) return;
+	if (outlier[id] != 1) {
+		out[id] = d0[id];
+		return;
+	}
+	const int x = (int)(id % W);
+	int dx = 0;
+	while (x + dx >= 0 && outlier[id + dx] != 0) dx--;
+	if (x + dx < 0) {
+		dx = 0;
+		while (x + dx < W && outlier[id + dx] != 0) dx++;
+	}
+	out[id] = (x + dx < W) ? d0[id + dx] : d0[id];
+}
+
+int interpolate_occlusion(const float *d0, const float *outlier, float *out, int H, int W, hipStream_t st)
+{
+	const int64_t size = (int64_t)H * W;
+	hipLaunchKernelGGL(interp_occ_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, d0, outlier, out, size, W);
+	return check_launch("interpolate_occlusion");
+}
+
+// ---- interpolate_mismatch, adcensus.cu:1001-1058 ----------------------------------------------
+// 16 rays; coordinates accumulate in float and are rounded half away from zero (CUDA round()).
+// If every ray leaves the image the reference reads an uninitialised value (assert compiled
+// out); defined here as "keep d0".
+__global__ void __launch_bounds__(256) interp_mis_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
+                                                         float *__restrict__ out, int64_t size, int H, int W)
+{
+	const float dir[32] = {0, 1, -0.5f, 1, -1, 1, -1, 0.5f, -1, 0, -1, -0.5f, -1, -1, -0.5f, -1,
+	                       0, -1, 0.5f, -1, 1, -1, 1, -0.5f, 1, 0, 1, 0.5f, 1, 1, 0.5f, 1};
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= size) return;
+	if (outlier[id] != 2) {
+		out[id] = d0[id];
+		return;
+	}
+	float vals[16];
+	int n = 0;
+	const int x = (int)(id % W), y = (int)(id / W);
+#pragma unroll
+	for (int d = 0; d < 16; ++d) {
+		const float dx = dir[2 * d], dy = dir[2 * d + 1];
+		float xx = (float)x, yy = (float)y;
+		int xi = (int)roundf(xx), yi = (int)roundf(yy);
+		while (0 <= yi && yi < H && 0 <= xi && xi < W && outlier[yi * W + xi] == 2) {
+			xx += dx;
+			yy += dy;
+			xi = (int)roundf(xx);
+			yi = (int)roundf(yy);
+		}
+		const bool inb = 0 <= yi && yi < H && 0 <= xi && xi < W;
+		// keep the array fully unrolled (registers): append via select chain
+		const float v = inb ? d0[yi * W + xi] : 0.0f;
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+			if (k == n && inb) vals[k] = v;
+		n += inb ? 1 : 0;
+	}
+	if (n == 0) {
+		out[id] = d0[id];
+		return;
+	}
+	// median = vals[n/2] of the ascending order (sort(), adcensus.cu:47-60): rank selection, ties are equal values
+	const int want = n / 2;
+	float res = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		if (i < n) {
+			int less = 0, eq = 0;
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				if (j < n) {
+					less += vals[j] < vals[i] ? 1 : 0;
+					eq += vals[j] == vals[i] ? 1 : 0;
+				}
+			}
+			if (less <= want && want < less + eq) res = vals[i];
+		}
+	}
+	out[id] = res;
+}
+
+int interpolate_mismatch(const float *d0, const float *outlier, float *out, int H, int W, hipStream_t st)
+{
+	const int64_t size = (int64_t)H * W;
+	hipLaunchKernelGGL(interp_mis_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, d0, outlier, out, size, H, W);
+	return check_launch("interpolate_mismatch");
+}
+
+// ---- subpixel_enchancement, adcensus.cu:1205-1220 ----------------------------------------------
+// cost of (pixel p, disparity d) is vol[d*sd + p*sp]: (D,H,W): sd=HW, sp=1 ; (H,W,ds): sd=1, sp=ds.
+__global__ void __launch_bounds__(256) subpixel_kernel(const float *__restrict__ d0, const float *__restrict__ c2,
+                                                       float *__restrict__ out, int64_t size, int64_t sd, int64_t sp, int disp_max)
+{
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= size) return;
+	const int d = (int)d0[id];
+	float res = (float)d;
+	if (1 <= d && d < disp_max - 1) {
+		const float cn = c2[(d - 1) * sd + id * sp];
+		const float cz = c2[d * sd + id * sp];
+		const float cp = c2[(d + 1) * sd + id * sp];
+		const float denom = 2 * (cp + cn - 2 * cz);
+		if ((double)denom > 1e-5) {
+			res = (float)((double)d - fmin(1.0, fmax(-1.0, (double)((cp - cn) / denom))));
+		}
+	}
+	out[id] = res;
+}
+
+int subpixel(const float *d0, const float *vol, float *out, int D, int H, int W, int64_t sd, int64_t sp, hipStream_t st)
+{
+	const int64_t size = (int64_t)H * W;
+	hipLaunchKernelGGL(subpixel_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, d0, vol, out, size, sd, sp, D);
+	return check_launch("subpixel_enchancement");
+}
+
+// ---- median2d, adcensus.cu:1575-1594 ------------------------------------------------------------
+// xs[n/2] of the ascending sort of the in-bounds taps: computed by rank counting (no NaNs
+// reach this stage, so any correct selection equals the reference's selection sort).
+template <int KR>
+__global__ void __launch_bounds__(256) median_kernel(const float *__restrict__ img, float *__restrict__ out, int H, int W)
+{
+	constexpr int K = 2 * KR + 1;
+	constexpr int TW = 64 + 2 * KR, TH = 4 + 2 * KR;
+	__shared__ float tile[TH][TW + 1];
+	const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
+	for (int i = threadIdx.x; i < TH * TW; i += 256) {
+		const int ty = i / TW, tx = i % TW;
+		const int gx = bx + tx - KR, gy = by + ty - KR;
+		tile[ty][tx] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(int64_t)gy * W + gx] : 0.0f;
+	}
+	__syncthreads();
+	const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+	const int x = bx + lx, y = by + ly;
+	if (x >= W || y >= H) return;
+	const int xa = max(0, x - KR), xb = min(W - 1, x + KR), ya = max(0, y - KR), yb = min(H - 1, y + KR);
+	const int n = (xb - xa + 1) * (yb - ya + 1);
+	const int want = n / 2;
+	float res = 0;
+	for (int i = 0; i < K * K; ++i) {
+		const int ix = x - KR + i / K, iy = y - KR + i % K;
+		if (ix < xa || ix > xb || iy < ya || iy > yb) continue;
+		const float vi = tile[iy - by + KR][ix - bx + KR];
+		int less = 0, eq = 0;
+		for (int yy = ya; yy <= yb; ++yy) {
+			for (int xx = xa; xx <= xb; ++xx) {
+				const float vj = tile[yy - by + KR][xx - bx + KR];
+				less += vj < vi ? 1 : 0;
+				eq += vj == vi ? 1 : 0;
+			}
+		}
+		if (less <= want && want < less + eq) {
+			res = vi;
+			break;
+		}
+	}
+	out[(int64_t)y * W + x] = res;
+}
+
+int median2d(const float *img, float *out, int H, int W, int k, hipStream_t st)
+{
+	const dim3 grid(cdiv(W, 64), cdiv(H, 4)), block(256);
+	switch (k / 2) {
+	case 0: hipLaunchKernelGGL(median_kernel<0>, grid, block, 0, st, img, out, H, W); break;
+	case 1: hipLaunchKernelGGL(median_kernel<1>, grid, block, 0, st, img, out, H, W); break;
+	case 2: hipLaunchKernelGGL(median_kernel<2>, grid, block, 0, st, img, out, H, W); break;
+	case 3: hipLaunchKernelGGL(median_kernel<3>, grid, block, 0, st, img, out, H, W); break;
+	case 4: hipLaunchKernelGGL(median_kernel<4>, grid, block, 0, st, img, out, H, W); break;
+	default: hipLaunchKernelGGL(median_kernel<5>, grid, block, 0, st, img, out, H, W); break;
+	}
+	return check_launch("median2d");
+}
+
+// ---- mean2d, adcensus.cu:1241-1261 ----------------------------------------------------------------
+// Range-gated Gaussian mean.  Tap order (xx outer, yy inner, running kernel index) and the
+// FMA-contracted `sum += img*k` are the reference's, so the result is bit-identical.
+// 64x8 output tile + halo staged in LDS; the (ks,ks) kernel is read through the scalar cache.
+__global__ void __launch_bounds__(256) mean2d_kernel(const float *__restrict__ img, const float *__restrict__ kernel,
+                                                     float *__restrict__ out, int H, int W, int kr, float alpha2)
+{
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	const int TW = 64 + 2 * kr, TH = 4 + 2 * kr;
+	const int TS = TW + 1;
+	const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
+	const float NANV = __builtin_nanf("");
+	for (int i = threadIdx.x; i < TH * TW; i += 256) {
+		const int ty = i / TW, tx = i - ty * TW;
+		const int gx = bx + tx - kr, gy = by + ty - kr;
+		// out-of-image taps become NaN: |NaN - c| < alpha2 is false, same effect as the bounds test
+		smem[ty * TS + tx] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(int64_t)gy * W + gx] : NANV;
+	}
+	__syncthreads();
+	const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+	const int x = bx + lx, y = by + ly;
+	if (x >= W || y >= H) return;
+	const float c = smem[(ly + kr) * TS + lx + kr];
+	float sum = 0, cnt = 0;
+	const int ks = 2 * kr + 1;
+	for (int ix = 0; ix < ks; ++ix) {
+		const float *col = smem + ly * TS + lx + ix;
+		const float *kcol = kernel + ix * ks;
+		for (int iy = 0; iy < ks; ++iy) {
+			const float v = col[iy * TS];
+			const float w = kcol[iy];
+			if (fabsf(v - c) < alpha2) {
+				sum = fmaf(v, w, sum);
+				cnt += w;
+			}
+		}
+	}
+	out[(int64_t)y * W + x] = sum / cnt;
+}
+
+int mean2d(const float *img, const float *kernel, float *out, int H, int W, int ks, float alpha2, hipStream_t st)
+{
+	const int kr = ks / 2;
+	const size_t lds = (size_t)(4 + 2 * kr) * (64 + 2 * kr + 1) * sizeof(float);
+	if (lds > 160 * 1024) {
+		set_error("mean2d: kernel size %d needs %zu B of LDS (> 160 KiB)", ks, lds);
+		return MC_EINVAL;
+	}
+	if (lds > 64 * 1024) {
+		hipError_t e = hipFuncSetAttribute((const void *)mean2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) {
+			set_error("mean2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
+			return (int)e;
+		}
+	}
+	hipLaunchKernelGGL(mean2d_kernel, dim3(cdiv(W, 64), cdiv(H, 4)), dim3(256), lds, st, img, kernel, out, H, W, kr, alpha2);
+	return check_launch("mean2d");
+}
+
+// ---- Normalize_forward, adcensus.cu:1284-1308 -------------------------------------------------------
+__global__ void __launch_bounds__(256) normalize_kernel(const float *__restrict__ in, float *__restrict__ norm, float *__restrict__ out,
+                                                        int C, int64_t HW, int64_t NHW)
+{
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= NHW) return;
+	const int64_t n = id / HW, p = id % HW;
+	const float *src = in + n * C * HW + p;
+	float sum = 0.0f;
+	for (int c = 0; c < C; ++c) {
+		const float x = src[c * HW];
+		sum = fmaf(x, x, sum);
+	}
+	const float nv = (float)((double)sum + 1e-5);
+	if (norm) norm[id] = nv;
+	const float r = sqrtf(nv);
+	float *dst = out + n * C * HW + p;
+	for (int c = 0; c < C; ++c) dst[c * HW] = src[c * HW] / r;
+}
+
+int normalize_forward(const float *in, float *norm, float *out, int N, int C, int H, int W, hipStream_t st)
+{
+	const int64_t HW = (int64_t)H * W;
+	hipLaunchKernelGGL(normalize_kernel, dim3(cdiv(N * HW, 256)), dim3(256), 0, st, in, norm, out, C, HW, N * HW);
+	return check_launch("normalize_forward");
+}
+
+}  // namespace mc

@@ -1,0 +1,240 @@
+// Matching-cost volumes from features (StereoJoin) and the ad / census baselines.
+//
+// StereoJoin_ (adcensus.cu:1455-1477): s(x,d) = -sum_c L[c,y,x] * R[c,y,x-d], accumulated
+// with c ascending as sum = fma(-L, R, sum) (nvcc contracts `sum -= a*b`); the value goes to
+// volL[d,y,x] and volR[d,y,x-d].  The fma chain order is kept, so results are bit-identical.
+#include "mc_common.h"
+
+namespace mc {
+
+// ---- v1: (D,H,W) outputs, one thread per (d,y,x), x fastest -------------------------------------
+// Reads of L and R and both stores are coalesced along x.  Only x-d >= 0 voxels are written
+// (the reference leaves the rest to the caller's NaN fill, main.lua:946).
+__global__ void __launch_bounds__(256) join_dhw_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
+                                                       float *__restrict__ volL, float *__restrict__ volR, int C, int D, int H, int W)
+{
+	const int x = blockIdx.x * 256 + threadIdx.x;
+	const int y = blockIdx.y;
+	const int d = blockIdx.z;
+	if (x >= W || x - d < 0) return;
+	const int64_t HW = (int64_t)H * W;
+	const int64_t id = (int64_t)y * W + x;
+	float sum = 0;
+	for (int c = 0; c < C; ++c) sum = fmaf(-fL[c * HW + id], fR[c * HW + id - d], sum);
+	volL[d * HW + id] = sum;
+	volR[d * HW + id - d] = sum;
+}
+
+int stereo_join_dhw(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int H, int W, hipStream_t st)
+{
+	hipLaunchKernelGGL(join_dhw_kernel, dim3(cdiv(W, 256), H, D), dim3(256), 0, st, fL, fR, volL, volR, C, D, H, W);
+	return check_launch("stereo_join");
+}
+
+// ---- (H,W,ds) outputs for the fused pipeline: banded L x R^T on the matrix cores ---------------------
+// Per image row y the cost band is S[x, x'] = -sum_c L[c,x] R[c,x'] for 0 <= x-x' < D: a dense
+// (banded) GEMM with K = C.  v_mfma_f32_32x32x2_f32 evaluates, per output element,
+// D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) (MI355X guide, "FP32-input MFMA": bit-for-bit a k-ordered
+// fmaf chain), so chaining the k-steps with c ascending reproduces StereoJoin_'s
+// `sum -= L*R` (adcensus.cu:1468-1471) bit for bit -- checked by tests/test_gpu_parity.py.
+//
+// One wave owns 32 consecutive OUTPUT pixels of one volume (the M side, operand A, negated
+// features held in VGPRs for the whole band) and walks the partner tiles of 32 pixels (N side,
+// operand B) that cover disparities 0..D-1.  The two volumes use opposite orientations so that
+// for either one a single accumulator register is, across lanes, a run of consecutive d of ONE
+// pixel, i.e. a contiguous 128-byte store into the (H,W,ds) volume:
+//   SIDE 0 (left  volume): M <-> x  (A = -L), N <-> x' (B = R), d = x - x' = m - n + 32*J
+//   SIDE 1 (right volume): M <-> x' (A = -R), N <-> x  (B = L), d = x - x' = n - m + 32*J
+// Every (pixel, d < D) voxel is written exactly once: NaN where the partner pixel is outside the
+// image (the reference's fill(0/0), main.lua:946).  fix_border is a separate small copy.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int SIDE, int KSTEPS>  // KSTEPS = ceil(C/2) rounded up to a supported size
+__global__ void __launch_bounds__(256) join_mfma_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
+                                                        float *__restrict__ vol, int C, int D, int ds, int H, int W,
+                                                        int tiles_per_row)
+{
+	const int lane = threadIdx.x & 63;
+	const int wid = threadIdx.x >> 6;
+	// XCD-aware mapping: blocks b and b+8k share an XCD (b % 8); give all blocks of one image
+	// row to one XCD so the row's features are fetched into one L2 only.
+	const int b = blockIdx.x;
+	const int xcd = b & 7, k = b >> 3;
+	const int blocks_per_row = (tiles_per_row + 3) >> 2;
+	const int y = (k / blocks_per_row) * 8 + xcd;
+	const int tile = (k % blocks_per_row) * 4 + wid;
+	if (y >= H || tile >= tiles_per_row) return;
+
+	const int64_t HW = (int64_t)H * W;
+	const float *__restrict__ fA = (SIDE == 0 ? fL : fR) + (int64_t)y * W;
+	const float *__restrict__ fB = (SIDE == 0 ? fR : fL) + (int64_t)y * W;
+	const int p0 = tile * 32;
+	const int nl = lane & 31, kh = lane >> 5;
+
+	// A operand: -feat[c = 2kk + kh][p0 + nl], zero outside the image / channel range
+	float a[KSTEPS];
+	{
+		const int px = p0 + nl;
+#pragma unroll
+		for (int kk = 0; kk < KSTEPS; ++kk) {
+			const int c = 2 * kk + kh;
+			a[kk] = (px < W && c < C) ? -fA[c * HW + px] : 0.0f;
+		}
+	}
+	const float NANV = __builtin_nanf("");
+	const int nJ = (D + 30) / 32 + 1;  // tiles J = 0..nJ-1 cover d up to 32*(nJ-1)+31 >= D-1
+	for (int J = 0; J < nJ; ++J) {
+		const int q0 = SIDE == 0 ? p0 - 32 * J : p0 + 32 * J;  // partner tile base
+		floatx16 acc;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+		const bool any_in = (q0 + 31 >= 0) && (q0 < W);  // wave-uniform
+		if (any_in) {
+			const int qx = q0 + nl;
+			const bool qin = qx >= 0 && qx < W;
+			float bv[KSTEPS];
+#pragma unroll
+			for (int kk = 0; kk < KSTEPS; ++kk) {
+				const int c = 2 * kk + kh;
+				bv[kk] = (qin && c < C) ? fB[c * HW + qx] : 0.0f;
+			}
+#pragma unroll
+			for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bv[kk], acc, 0, 0, 0);
+		}
+		// C/D layout: col n = lane & 31, row m = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+		const int qn = q0 + nl;  // partner pixel of this lane's column
+		const bool qok = qn >= 0 && qn < W;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const int m = (i & 3) + 8 * (i >> 2) + 4 * kh;
+			const int px = p0 + m;
+			const int d = SIDE == 0 ? m - nl + 32 * J : nl - m + 32 * J;
+			if (px < W && d >= 0 && d < D) vol[((int64_t)y * W + px) * ds + d] = qok ? acc[i] : NANV;
+		}
+	}
+}
+
+// fix_border (main.lua:922-927) on (H,W,ds): the n outermost pixels of one side replicate the
+// (n+1)-th pixel's whole cost vector.  One wave per (row, border pixel).
+__global__ void __launch_bounds__(256) fix_border_hwd_kernel(float *__restrict__ vol, int D, int ds, int H, int W, int n,
+                                                             int direction)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (w >= (int64_t)H * n) return;
+	const int y = (int)(w / n), i = (int)(w % n) + 1;
+	const int dst = direction < 0 ? W - i : i - 1;
+	const int src = direction < 0 ? W - (n + 1) : n;
+	const float *s = vol + ((int64_t)y * W + src) * ds;
+	float *t = vol + ((int64_t)y * W + dst) * ds;
+	for (int d = lane; d < D; d += 64) t[d] = s[d];
+}
+
+int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int ds, int H, int W, int n,
+                    hipStream_t st)
+{
+	const int tiles = (W + 31) / 32;
+	const int blocks_per_row = (tiles + 3) / 4;
+	const int rows8 = (H + 7) / 8;
+	const dim3 grid((unsigned)(rows8 * blocks_per_row * 8)), block(256);
+	const int ks = (C + 1) / 2;
+#define MC_JOIN_LAUNCH(KS)                                                                                                  \
+	do {                                                                                                                    \
+		hipLaunchKernelGGL((join_mfma_kernel<0, KS>), grid, block, 0, st, fL, fR, volL, C, D, ds, H, W, tiles);              \
+		hipLaunchKernelGGL((join_mfma_kernel<1, KS>), grid, block, 0, st, fL, fR, volR, C, D, ds, H, W, tiles);              \
+	} while (0)
+	if (ks <= 8) MC_JOIN_LAUNCH(8);
+	else if (ks <= 16) MC_JOIN_LAUNCH(16);
+	else if (ks <= 32) MC_JOIN_LAUNCH(32);
+	else if (ks <= 56) MC_JOIN_LAUNCH(56);
+	else MC_JOIN_LAUNCH(64);
+#undef MC_JOIN_LAUNCH
+	int rc = check_launch("stereo_join_hwd");
+	if (rc || n <= 0) return rc;
+	hipLaunchKernelGGL(fix_border_hwd_kernel, dim3(cdiv((int64_t)H * n * 64, 256)), block, 0, st, volL, D, ds, H, W, n, -1);
+	hipLaunchKernelGGL(fix_border_hwd_kernel, dim3(cdiv((int64_t)H * n * 64, 256)), block, 0, st, volR, D, ds, H, W, n, 1);
+	return check_launch("fix_border_hwd");
+}
+
+// ---- ad, adcensus.cu:62-93 ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ad_kernel(const float *__restrict__ x0, const float *__restrict__ x1, float *__restrict__ out,
+                                                 int64_t size, int H, int W, int direction)
+{
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= size) return;
+	int64_t t = id;
+	const int x = (int)(t % W);
+	t /= W;
+	const int y = (int)(t % H);
+	t /= H;
+	const int d = (int)t * direction;
+	float dist;
+	if (0 <= x + d && x + d < W) {
+		int cnt = 0;
+		dist = 0;
+		for (int yy = y - 4; yy <= y + 4; yy++) {
+			for (int xx = x - 4; xx <= x + 4; xx++) {
+				if (0 <= xx && xx < W && 0 <= xx + d && xx + d < W && 0 <= yy && yy < H) {
+					const int ind = yy * W + xx;
+					dist += fabsf(x0[ind] - x1[ind + d]);
+					cnt++;
+				}
+			}
+		}
+		dist /= cnt;
+	} else {
+		dist = __builtin_nanf("");
+	}
+	out[id] = dist;
+}
+
+int ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, hipStream_t st)
+{
+	const int64_t size = (int64_t)D * H * W;
+	hipLaunchKernelGGL(ad_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, x0, x1, vol, size, H, W, direction);
+	return check_launch("ad");
+}
+
+// ---- census, adcensus.cu:117-153 -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) census_kernel(const float *__restrict__ x0, const float *__restrict__ x1,
+                                                     float *__restrict__ out, int64_t size, int Cimg, int H, int W, int direction)
+{
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= size) return;
+	int64_t t = id;
+	const int x = (int)(t % W);
+	t /= W;
+	const int y = (int)(t % H);
+	t /= H;
+	const int d = (int)t * direction;
+	float dist;
+	if (0 <= x + d && x + d < W) {
+		dist = 0;
+		for (int i = 0; i < Cimg; i++) {
+			const int ind_p = (i * H + y) * W + x;
+			for (int yy = y - 4; yy <= y + 4; yy++) {
+				for (int xx = x - 4; xx <= x + 4; xx++) {
+					if (0 <= xx && xx < W && 0 <= xx + d && xx + d < W && 0 <= yy && yy < H) {
+						const int ind_q = (i * H + yy) * W + xx;
+						if ((x0[ind_q] < x0[ind_p]) != (x1[ind_q + d] < x1[ind_p + d])) dist++;
+					} else {
+						dist++;
+					}
+				}
+			}
+		}
+		dist /= Cimg;
+	} else {
+		dist = __builtin_nanf("");
+	}
+	out[id] = dist;
+}
+
+int census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, hipStream_t st)
+{
+	const int64_t size = (int64_t)D * H * W;
+	hipLaunchKernelGGL(census_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, x0, x1, vol, size, Cimg, H, W, direction);
+	return check_launch("census");
+}
+
+}  // namespace mc

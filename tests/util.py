@@ -1,0 +1,84 @@
+"""Seeded synthetic inputs shared by the parity tests (shapes follow SURVEY.md section 8d)."""
+import numpy as np
+
+
+def normalize_image(img):
+    """x:add(-x:mean()):div(x:std()) with torch's unbiased std, main.lua:1095-1096."""
+    img = img.astype(np.float64)
+    return ((img - img.mean()) / img.std(ddof=1)).astype(np.float32)
+
+
+def smooth_pair(H, W, D, seed=1234, noise=0.05):
+    """Left = blurred N(0,1) field; right = left shifted by a smooth disparity field + noise."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    left = gaussian_filter(rng.standard_normal((H, W + D)), 3.0)
+    disp = gaussian_filter(rng.random((H, W + D)), 12.0)
+    disp = (disp - disp.min()) / (disp.max() - disp.min() + 1e-12) * 0.8 * (D - 1)
+    xs = np.arange(W + D)[None, :] + disp
+    x0 = np.floor(xs).astype(int).clip(0, W + D - 1)
+    x1 = (x0 + 1).clip(0, W + D - 1)
+    f = xs - np.floor(xs)
+    rows = np.arange(H)[:, None]
+    right = left[rows, x0] * (1 - f) + left[rows, x1] * f
+    right = right + noise * rng.standard_normal(right.shape)
+    return normalize_image(left[:, :W]), normalize_image(right[:, :W])
+
+
+def random_pair(H, W, seed=0):
+    rng = np.random.default_rng(seed)
+    return (normalize_image(rng.standard_normal((H, W))), normalize_image(rng.standard_normal((H, W))))
+
+
+def blocky_pair(H, W, seed=0, levels=4):
+    """Piecewise-constant images: long cross arms and many exact intensity ties."""
+    rng = np.random.default_rng(seed)
+    def one():
+        small = rng.integers(0, levels, size=((H + 7) // 8, (W + 7) // 8)).astype(np.float32)
+        return np.kron(small, np.ones((8, 8), np.float32))[:H, :W] * 0.25
+    return one(), one()
+
+
+def features(C, H, W, seed=42):
+    """rng(seed) N(0,1) (2,C,H,W) L2-normalised over C (Normalize2 semantics, eps 1e-5)."""
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((2, C, H, W)).astype(np.float32)
+    n = np.sqrt((f.astype(np.float64) ** 2).sum(1, keepdims=True) + 1e-5)
+    return (f / n).astype(np.float32)
+
+
+def raw_volumes(D, H, W, seed=7):
+    """uniform[0,1) (sigmoid range) with the NaN triangles: left d > x, right x + d >= W."""
+    rng = np.random.default_rng(seed)
+    vl = rng.random((D, H, W), dtype=np.float32)
+    vr = rng.random((D, H, W), dtype=np.float32)
+    d = np.arange(D)[:, None, None]
+    x = np.arange(W)[None, None, :]
+    vl[np.broadcast_to(d > x, vl.shape)] = np.nan
+    vr[np.broadcast_to(x + d >= W, vr.shape)] = np.nan
+    return vl, vr
+
+
+def same_bits(a, b):
+    """Bit-exact equality with NaN == NaN (NaN masks must match exactly)."""
+    a = np.ascontiguousarray(a, np.float32).ravel()
+    b = np.ascontiguousarray(b, np.float32).ravel()
+    if a.shape != b.shape:
+        return False
+    na, nb = np.isnan(a), np.isnan(b)
+    if not np.array_equal(na, nb):
+        return False
+    return np.array_equal(a[~na].view(np.uint32), b[~nb].view(np.uint32))
+
+
+def diff_report(a, b, name=""):
+    a = np.asarray(a, np.float32).ravel()
+    b = np.asarray(b, np.float32).ravel()
+    na, nb = np.isnan(a), np.isnan(b)
+    bad_nan = int((na != nb).sum())
+    ok = ~(na | nb)
+    neq = ok & (a.view(np.uint32) != b.view(np.uint32))
+    md = float(np.abs(a[ok] - b[ok]).max()) if ok.any() else 0.0
+    first = np.flatnonzero(neq | (na != nb))[:5]
+    return "%s: nan-mask mismatches=%d, value mismatches=%d / %d, max|diff|=%g, first idx=%s a=%s b=%s" % (
+        name, bad_nan, int(neq.sum()), a.size, md, first.tolist(), a[first].tolist(), b[first].tolist())
