@@ -1,0 +1,76 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/mc_adcensus.h declares,
+and validates arguments before touching the device (bad arguments return MC_EINVAL with a message,
+where the reference raises a Lua error)."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "mc_adcensus.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(mc):
+    names = header_symbols()
+    assert len(names) >= 27
+    lib = C.CDLL(mc._lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libmcadcensus.so does not export %s" % n
+    assert sorted(mc._lib.SYMBOLS) == names, "ctypes binding and header disagree"
+
+
+def test_only_the_abi_is_exported(mc):
+    """-fvisibility=hidden: nothing but mc_* leaves the library (no C++ or torch types in the ABI)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", mc._lib.LIB_PATH]).decode()
+    syms = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert syms and all(s.startswith("mc_") for s in syms), syms
+
+
+def test_version_and_struct_layout(mc):
+    assert mc._lib.lib.mc_version() == 1
+    # mc_params is plain C: 4-byte fields, one double (8-aligned)
+    assert C.sizeof(mc.params.McParams) == 72
+
+
+def test_bad_arguments_fail_loudly_without_a_gpu(mc):
+    lib = mc._lib.lib
+    EINVAL = -22
+    assert lib.mc_median2d(1, 2, 8, 8, 4, None) == EINVAL           # even kernel size (adcensus.cu:1601)
+    assert b"odd" in lib.mc_last_error()
+    assert lib.mc_cbca(1, 1, 1, 1, 4, 8, 8, -1, None) == EINVAL       # in == out
+    assert lib.mc_sgm2(1, 1, 1, 2, 1, 0, 8, 8, 600, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, -1, None) == EINVAL  # D > 512
+    assert lib.mc_sgm2(1, 1, 1, 2, 1, 0, 8, 8, 16, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, -1, None) == EINVAL   # tmp too small
+    assert lib.mc_stereo_join(1, 1, 1, 1, 200, 4, 8, 8, None) == EINVAL  # C > 128 (adcensus.cu:1460)
+    assert lib.mc_cross(None, 1, 8, 8, 1, 0.5, None) == EINVAL
+    assert lib.mc_ad(1, 1, 1, 4, 8, 8, 0, None) == EINVAL              # direction must be -1 / +1
+    p = mc.make_params("kitti_fast")
+    assert lib.mc_predict_workspace_bytes(C.byref(p), 64, 228, 370, 1226) > 4 * 4 * 228 * 370 * 1226
+    assert lib.mc_predict(C.byref(p), 1, 1, None, None, 0, None, None, 8, 8, 8, 256, 1 << 30, None, None, None, None, 1,
+                          None) == EINVAL                              # neither features nor raw volumes
+
+
+def test_gaussian_host_matches_main_lua(mc):
+    """gaussian(sigma), main.lua:528-540, runs on the host in doubles: checked here without a GPU."""
+    import math
+    import numpy as np
+    k = mc.adcensus.gaussian(1.67).numpy()
+    kr = math.ceil(1.67 * 3)
+    assert k.shape == (2 * kr + 1, 2 * kr + 1)
+    want = np.array([[math.exp(-(x * x + y * y) / (2 * 1.67 * 1.67)) for x in range(-kr, kr + 1)]
+                     for y in range(-kr, kr + 1)]).astype(np.float32)
+    assert (k == want).all()
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through the CPU oracle (tests / smoke / bench baseline only)."""
+    pkg = os.path.join(ROOT, "mc-cnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".lua")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "cpu_oracle" not in txt and "mc_oracle" not in txt and "ref_lib" not in txt, f
