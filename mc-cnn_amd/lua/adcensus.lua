@@ -1,0 +1,162 @@
+--[[ adcensus.lua -- LuaJIT-FFI shim that rebuilds the reference's `adcensus` table
+(luaopen_libadcensus, adcensus.cu:2061-2105) on top of libmcadcensus.so, the MI355X (gfx950)
+C-ABI library of this repository (include/mc_adcensus.h).
+
+Usage in main.lua (replaces `require 'libadcensus'`, main.lua:327):
+
+    adcensus = require 'adcensus'          -- this file, with libmcadcensus.so on the library path
+
+Every function keeps the reference's name, argument order and in-place / allocate-and-return
+behaviour, so stereo_predict (main.lua:929-1082) runs unchanged.  Tensors are torch.CudaTensor
+(hipified cutorch on ROCm); like the reference, contiguous 4-D float tensors are assumed
+(adcensus.cu reads raw THCudaTensor_data); unlike it, contiguity is checked.  A non-zero return
+code becomes error(mc_last_error()), where the reference calls luaL_error after
+cudaPeekAtLastError (adcensus.cu:31-36).  All launches go to the NULL stream, which is the
+stream the reference's kernels and cutorch's default stream use.
+
+NOTE: LuaJIT/Torch7 are not available in the build image of this repository, so this file is
+exercised only by review; the identical C ABI is driven from Python ctypes in tests/.
+]]
+local ffi = require 'ffi'
+
+ffi.cdef[[
+int mc_version(void);
+const char *mc_last_error(void);
+int mc_fill_nan(float *p, int64_t n, void *stream);
+int mc_stereo_join(const float *featL, const float *featR, float *volL, float *volR, int C, int D, int H, int W, void *stream);
+int mc_ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, void *stream);
+int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, void *stream);
+int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream);
+int mc_cross(const float *img, float *arms, int H, int W, int L1, float tau1, void *stream);
+int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction, void *stream);
+size_t mc_sgm2_tmp_bytes(int H, int W, int D);
+int mc_sgm2(const float *x0, const float *x1, const float *in_hwd, float *out_hwd, void *tmp, size_t tmp_bytes,
+            int H, int W, int D, float pi1, float pi2, float tau_so, float alpha1, float sgm_q1, float sgm_q2,
+            int direction, void *stream);
+int mc_spatial_argmin(const float *vol, float *out, int D, int H, int W, void *stream);
+int mc_outlier_detection(const float *d0, const float *d1, float *outlier, int H, int W, int disp_max, void *stream);
+int mc_interpolate_occlusion(const float *d0, const float *outlier, float *out, int H, int W, void *stream);
+int mc_interpolate_mismatch(const float *d0, const float *outlier, float *out, int H, int W, void *stream);
+int mc_subpixel_enchancement(const float *d0, const float *vol, float *out, int D, int H, int W, void *stream);
+int mc_median2d(const float *img, float *out, int H, int W, int kernel_size, void *stream);
+int mc_mean2d(const float *img, const float *kernel, float *out, int H, int W, int ks, float alpha2, void *stream);
+int mc_normalize_forward(const float *in, float *norm, float *out, int N, int C, int H, int W, void *stream);
+]]
+
+local lib = ffi.load('mcadcensus')
+assert(lib.mc_version() == 1, 'libmcadcensus ABI version mismatch')
+
+local function check(rc, what)
+   if rc ~= 0 then
+      error(('%s: %s (rc=%d)'):format(what, ffi.string(lib.mc_last_error()), rc), 3)
+   end
+end
+
+-- luaT_checkudata(L, i, "torch.CudaTensor") + the contiguity the reference silently assumes
+local function ptr(t, what)
+   if torch.typename(t) ~= 'torch.CudaTensor' then
+      error(('%s: torch.CudaTensor expected, got %s'):format(what, torch.typename(t) or type(t)), 3)
+   end
+   if not t:isContiguous() then
+      error(what .. ': contiguous tensor expected', 3)
+   end
+   return t:data()   -- float* device pointer (cutorch FFI)
+end
+
+local function like(x)   -- new_tensor_like, adcensus.cu:40-45
+   return torch.CudaTensor():resizeAs(x)
+end
+
+local adcensus = {}
+
+function adcensus.ad(x0, x1, out, direction)                 -- adcensus.cu:95-114
+   check(lib.mc_ad(ptr(x0, 'ad'), ptr(x1, 'ad'), ptr(out, 'ad'), out:size(2), out:size(3), out:size(4), direction, nil), 'ad')
+end
+
+function adcensus.census(x0, x1, out, direction)             -- adcensus.cu:155-175
+   check(lib.mc_census(ptr(x0, 'census'), ptr(x1, 'census'), ptr(out, 'census'), x0:size(2),
+                       out:size(2), out:size(3), out:size(4), direction, nil), 'census')
+end
+
+function adcensus.StereoJoin(input_L, input_R, output_L, output_R)   -- adcensus.cu:1479-1498
+   check(lib.mc_stereo_join(ptr(input_L, 'StereoJoin'), ptr(input_R, 'StereoJoin'), ptr(output_L, 'StereoJoin'),
+                            ptr(output_R, 'StereoJoin'), input_L:size(2), output_L:size(2), output_L:size(3),
+                            output_L:size(4), nil), 'StereoJoin')
+end
+
+function adcensus.cross(x0, out, L1, tau1)                   -- adcensus.cu:324-341
+   check(lib.mc_cross(ptr(x0, 'cross'), ptr(out, 'cross'), out:size(3), out:size(4), L1, tau1, nil), 'cross')
+end
+
+function adcensus.cbca(x0c, x1c, vol_in, vol_out, direction) -- adcensus.cu:379-400
+   check(lib.mc_cbca(ptr(x0c, 'cbca'), ptr(x1c, 'cbca'), ptr(vol_in, 'cbca'), ptr(vol_out, 'cbca'),
+                     vol_out:size(2), vol_out:size(3), vol_out:size(4), direction, nil), 'cbca')
+end
+
+-- adcensus.sgm2, adcensus.cu:620-697.  `tmp` is the reference's (W,D) line-state tensor; this
+-- library keeps line state in registers and needs a differently sized scratch (edge-class maps),
+-- so `tmp` is resized to that many floats (a CudaTensor the caller already owns and reuses).
+function adcensus.sgm2(x0, x1, input, output, tmp, pi1, pi2, tau_so, alpha1, sgm_q1, sgm_q2, direction)
+   local H, W, D = input:size(2), input:size(3), input:size(4)
+   local need = tonumber(lib.mc_sgm2_tmp_bytes(H, W, D))
+   if tmp:nElement() * 4 < need then tmp:resize(math.ceil(need / 4)) end
+   check(lib.mc_sgm2(ptr(x0, 'sgm2'), ptr(x1, 'sgm2'), ptr(input, 'sgm2'), ptr(output, 'sgm2'), ptr(tmp, 'sgm2'),
+                     tmp:nElement() * 4, H, W, D, pi1, pi2, tau_so, alpha1, sgm_q1, sgm_q2, direction, nil), 'sgm2')
+end
+
+function adcensus.spatial_argmin(input, output)              -- adcensus.cu:264-278
+   check(lib.mc_spatial_argmin(ptr(input, 'spatial_argmin'), ptr(output, 'spatial_argmin'),
+                               input:size(2), input:size(3), input:size(4), nil), 'spatial_argmin')
+end
+
+function adcensus.outlier_detection(d0, d1, outlier, disp_max)   -- adcensus.cu:901-918
+   check(lib.mc_outlier_detection(ptr(d0, 'outlier_detection'), ptr(d1, 'outlier_detection'),
+                                  ptr(outlier, 'outlier_detection'), d0:size(3), d0:size(4), disp_max, nil),
+         'outlier_detection')
+end
+
+function adcensus.interpolate_occlusion(d0, outlier)         -- adcensus.cu:1107-1125
+   local out = like(d0)
+   check(lib.mc_interpolate_occlusion(ptr(d0, 'interpolate_occlusion'), ptr(outlier, 'interpolate_occlusion'),
+                                      out:data(), d0:size(3), d0:size(4), nil), 'interpolate_occlusion')
+   return out
+end
+
+function adcensus.interpolate_mismatch(d0, outlier)          -- adcensus.cu:1060-1077
+   local out = like(d0)
+   check(lib.mc_interpolate_mismatch(ptr(d0, 'interpolate_mismatch'), ptr(outlier, 'interpolate_mismatch'),
+                                     out:data(), d0:size(3), d0:size(4), nil), 'interpolate_mismatch')
+   return out
+end
+
+function adcensus.subpixel_enchancement(d0, c2, disp_max)    -- adcensus.cu:1222-1239
+   local out = like(d0)
+   check(lib.mc_subpixel_enchancement(ptr(d0, 'subpixel_enchancement'), ptr(c2, 'subpixel_enchancement'),
+                                      out:data(), disp_max, d0:size(3), d0:size(4), nil), 'subpixel_enchancement')
+   return out
+end
+
+function adcensus.median2d(img, kernel_size)                 -- adcensus.cu:1596-1613
+   local out = like(img)
+   check(lib.mc_median2d(ptr(img, 'median2d'), out:data(), img:size(3), img:size(4), kernel_size, nil), 'median2d')
+   return out
+end
+
+function adcensus.mean2d(img, kernel, alpha2)                -- adcensus.cu:1263-1282
+   local out = like(img)
+   check(lib.mc_mean2d(ptr(img, 'mean2d'), ptr(kernel, 'mean2d'), out:data(), img:size(3), img:size(4),
+                       kernel:size(1), alpha2, nil), 'mean2d')
+   return out
+end
+
+function adcensus.Normalize_forward(input, norm, output)     -- adcensus.cu:1310-1333
+   check(lib.mc_normalize_forward(ptr(input, 'Normalize_forward'), ptr(norm, 'Normalize_forward'),
+                                  ptr(output, 'Normalize_forward'), input:size(1), input:size(2), input:size(3),
+                                  input:size(4), nil), 'Normalize_forward')
+end
+
+function adcensus.version()                                  -- adcensus.cu:2055-2059
+   print(('libmcadcensus (MI355X) ABI version %d'):format(lib.mc_version()))
+end
+
+return adcensus
