@@ -32,9 +32,9 @@ int cross(const float *img, float *arms, int H, int W, int L1, float tau1, hipSt
 int cbca(const float *x0c, const float *x1c, const float *vin, float *vout, int D, int H, int W, int direction, hipStream_t st);
 size_t sgm_maps_bytes(int H, int W);
 int sgm_prep(const float *x0, const float *x1, void *maps, int H, int W, float tau_so, hipStream_t st);
-int sgm_sweeps(const float *const C[2], float *const out[2], float *const disp[2], const int direction[2], int nvol, int H,
-               int W, int D, int ds, const void *maps, float pi1, float pi2, float alpha1, float q1, float q2, bool fused,
-               hipStream_t st);
+int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2], float *const disp[2],
+               const int direction[2], int nvol, int H, int W, int D, int ds, const void *maps, float pi1, float pi2,
+               float alpha1, float q1, float q2, bool fused, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -102,7 +102,7 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	const int kr = (int)ceil(p->blur_sigma * 3);
 	const int ks = 2 * kr + 1;
 	pl.gk = align_up((size_t)ks * ks * sizeof(float), 256);
-	pl.total = pl.maps + pl.arms + 4 * pl.vol + 6 * pl.img + pl.gk;
+	pl.total = pl.maps + pl.arms + 6 * pl.vol + 6 * pl.img + pl.gk;
 	return pl;
 }
 
@@ -165,6 +165,9 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	bufA[1] = (float *)w; w += pl.vol;
 	bufB[0] = (float *)w; w += pl.vol;
 	bufB[1] = (float *)w; w += pl.vol;
+	float *bufC[2];  // scratch of the SGM's concurrent second direction
+	bufC[0] = (float *)w; w += pl.vol;
+	bufC[1] = (float *)w; w += pl.vol;
 	float *img[6];
 	for (int i = 0; i < 6; ++i) { img[i] = (float *)w; w += pl.img; }
 	float *gk = (float *)w;
@@ -239,7 +242,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 			const float *Cv[2] = {cur[0], cur[1]};
 			float *outv[2] = {other(0), other(1)};
 			const bool am = (it == p->sgm_i - 1) && p->cbca_i2 == 0;
-			RUN(sgm_sweeps(Cv, outv, am ? dispv : nullptr, direction, 2, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
+			RUN(sgm_sweeps(Cv, outv, bufC, am ? dispv : nullptr, direction, 2, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
 			               p->sgm_q1, p->sgm_q2, true, st));
 			have_disp = am;
 			cur[0] = outv[0]; cur[1] = outv[1];
@@ -404,7 +407,7 @@ int mc_sgm2(const float *x0, const float *x1, const float *in_hwd, float *out_hw
 	const float *Cv[2] = {in_hwd, in_hwd};
 	float *outv[2] = {out_hwd, out_hwd};
 	const int dirv[2] = {direction, direction};
-	return sgm_sweeps(Cv, outv, nullptr, dirv, 1, H, W, D, D, tmp, pi1, pi2, alpha1, sgm_q1, sgm_q2, false, st);
+	return sgm_sweeps(Cv, outv, nullptr, nullptr, dirv, 1, H, W, D, D, tmp, pi1, pi2, alpha1, sgm_q1, sgm_q2, false, st);
 }
 
 int mc_dhw_to_hwd(const float *in, float *out, int D, int H, int W, void *stream)

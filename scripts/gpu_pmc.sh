@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage: bash scripts/gpu_pmc.sh <tag> <config> [steps]
+# HBM-traffic and stall counters per kernel: separate rocprofv3 --pmc passes (MI355X_MICROARCH.md: FETCH_SIZE
+# needs 3 TCC slots, WRITE_SIZE 2 -> one pass each), kernel-trace only, CSV output.
+TAG=$1; CFG=$2; STEPS=${3:-3}
+O=$GRAFT_REPO_ROOT/gpurun_out/$TAG/pmc_$CFG; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+i=0
+for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $O/p$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline > $O/p$i.log 2>&1
+  echo "pass $i ($SET) rc=$?"
+done
+find $O -name "*.csv" | head -20
