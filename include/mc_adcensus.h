@@ -80,6 +80,13 @@ int mc_cross(const float *img, float *arms, int H, int W, int L1, float tau1, vo
 int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
             int D, int H, int W, int direction, void *stream);
 
+/* The same operator on the fast path: arm lengths are packed into `scratch` (mc_cbca_scratch_bytes) and the
+ * region sums run out of LDS-staged tiles; same accumulation order, bit-identical to mc_cbca.  Tiles whose
+ * arms exceed the staged halo (16 pixels here) fall back to mc_cbca's loop inside the same launch. */
+size_t mc_cbca_scratch_bytes(int H, int W);
+int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
+               int D, int H, int W, int direction, void *scratch, size_t scratch_bytes, void *stream);
+
 /* ---- semiglobal matching ------------------------------------------------ */
 
 /* Bytes of scratch mc_sgm2 needs in `tmp` (edge-class maps; the reference's

@@ -62,8 +62,27 @@ def cross(x0, out, L1, tau1):
     check(lib.mc_cross(_p(x0), _p(out), H, W, int(L1), float(tau1), _stream()), "cross")
 
 
+def _scratch_for(device, need):
+    key = (device.index, need)
+    scratch = _scratch.get(key)
+    if scratch is None:
+        scratch = _scratch[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return scratch
+
+
 def cbca(x0c, x1c, vol_in, vol_out, direction):
-    """adcensus.cbca(x0c, x1c, vol_in, vol_out, direction) -- adcensus.cu:379-400."""
+    """adcensus.cbca(x0c, x1c, vol_in, vol_out, direction) -- adcensus.cu:379-400.  Runs the LDS-tiled kernel
+    (mc_cbca_ws) with a cached per-shape scratch for the packed arm lengths."""
+    _chk(x0c, x1c, vol_in, vol_out)
+    D, H, W = vol_out.shape[-3:]
+    need = lib.mc_cbca_scratch_bytes(H, W)
+    scratch = _scratch_for(vol_out.device, need)
+    check(lib.mc_cbca_ws(_p(x0c), _p(x1c), _p(vol_in), _p(vol_out), D, H, W, int(direction), scratch.data_ptr(), need,
+                         _stream()), "cbca")
+
+
+def cbca_reference_shaped(x0c, x1c, vol_in, vol_out, direction):
+    """The same operator through mc_cbca (one thread per voxel, no scratch)."""
     _chk(x0c, x1c, vol_in, vol_out)
     D, H, W = vol_out.shape[-3:]
     check(lib.mc_cbca(_p(x0c), _p(x1c), _p(vol_in), _p(vol_out), D, H, W, int(direction), _stream()), "cbca")

@@ -30,6 +30,12 @@ int ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int di
 int census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, hipStream_t st);
 int cross(const float *img, float *arms, int H, int W, int L1, float tau1, hipStream_t st);
 int cbca(const float *x0c, const float *x1c, const float *vin, float *vout, int D, int H, int W, int direction, hipStream_t st);
+size_t cbca_scratch_bytes(int H, int W);
+int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st);
+int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
+                     int direction, hipStream_t st);
+int cbca_tiled(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
+               hipStream_t st);
 size_t sgm_maps_bytes(int H, int W);
 int sgm_prep(const float *x0, const float *x1, void *maps, int H, int W, float tau_so, hipStream_t st);
 int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2], float *const disp[2],
@@ -86,7 +92,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 struct Plan {
 	int Dp;                 // padded pixel stride of the (H,W,Dp) volumes
-	size_t maps, arms, vol, img, gk;
+	size_t maps, arms, pack, vol, img, gk;
 	size_t total;
 };
 
@@ -97,12 +103,13 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	const size_t HW = (size_t)H * W;
 	pl.maps = align_up(sgm_maps_bytes(H, W), 256);
 	pl.arms = align_up(8 * HW * sizeof(float), 256);
+	pl.pack = cbca_scratch_bytes(H, W);
 	pl.vol = align_up((size_t)pl.Dp * HW * sizeof(float), 256);
 	pl.img = align_up(HW * sizeof(float), 256);
 	const int kr = (int)ceil(p->blur_sigma * 3);
 	const int ks = 2 * kr + 1;
 	pl.gk = align_up((size_t)ks * ks * sizeof(float), 256);
-	pl.total = pl.maps + pl.arms + 6 * pl.vol + 6 * pl.img + pl.gk;
+	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk;
 	return pl;
 }
 
@@ -160,6 +167,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	char *w = (char *)workspace;
 	void *maps = w; w += pl.maps;
 	float *x0c = (float *)w; float *x1c = x0c + 4 * HW; w += pl.arms;
+	void *packed = w; w += pl.pack;
 	float *bufA[2], *bufB[2];
 	bufA[0] = (float *)w; w += pl.vol;
 	bufA[1] = (float *)w; w += pl.vol;
@@ -184,7 +192,9 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	if (use_cbca) {  // main.lua:993-996: x0c from the LEFT image, x1c from the RIGHT, for both directions
 		RUN(cross(x0, x0c, H, W, p->L1, p->tau1, st));
 		RUN(cross(x1, x1c, H, W, p->L1, p->tau1, st));
+		RUN(cbca_pack(x0c, x1c, packed, H, W, st));
 	}
+	const int cbca_cap = p->L1 - 1;  // cross(): an arm never exceeds L1-1 pixels (adcensus.cu:314)
 	tm.mark(ST_PREP);
 
 	// ---- (A) cost volumes + CBCA-1; ends with cur[v] and its layout ----
@@ -216,7 +226,8 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		for (int i = 0; i < p->cbca_i1; ++i) {  // main.lua:998-1001 (ping-pong instead of vol:copy(tmp))
 			for (int v = 0; v < 2; ++v) {
 				float *dst = other(v);
-				RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));
+				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29)) RUN(cbca_tiled(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
+				else RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));  // packed lengths saturate at 255
 				cur[v] = dst;
 			}
 		}
@@ -262,7 +273,8 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		for (int i = 0; i < p->cbca_i2; ++i) {
 			for (int v = 0; v < 2; ++v) {
 				float *dst = other(v);
-				RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));
+				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29)) RUN(cbca_tiled(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
+				else RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));  // packed lengths saturate at 255
 				cur[v] = dst;
 			}
 		}
@@ -383,6 +395,31 @@ int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_
 	MC_REQUIRE(dims_ok(D, H, W) && D <= 65535, "mc_cbca: bad dims");
 	MC_REQUIRE(direction == -1 || direction == 1, "mc_cbca: direction must be -1 or 1");
 	return cbca(x0c, x1c, vol_in, vol_out, D, H, W, direction, as_stream(stream));
+}
+
+size_t mc_cbca_scratch_bytes(int H, int W)
+{
+	if (H < 1 || W < 1) return 0;
+	return cbca_scratch_bytes(H, W);
+}
+
+int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
+               void *scratch, size_t scratch_bytes, void *stream)
+{
+	MC_REQUIRE(x0c && x1c && vol_in && vol_out && scratch, "mc_cbca_ws: null pointer");
+	MC_REQUIRE(vol_in != vol_out, "mc_cbca_ws: in-place aggregation is not supported (the reference uses a tmp volume too)");
+	MC_REQUIRE(dims_ok(D, H, W) && D <= 65535 * 8, "mc_cbca_ws: bad dims");
+	MC_REQUIRE(direction == -1 || direction == 1, "mc_cbca_ws: direction must be -1 or 1");
+	MC_REQUIRE(scratch_bytes >= cbca_scratch_bytes(H, W), "mc_cbca_ws: scratch holds %zu bytes, needs %zu", scratch_bytes,
+	           cbca_scratch_bytes(H, W));
+	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws: scratch must be 4-byte aligned");
+	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29), "mc_cbca_ws: image too large for 32-bit plane offsets (use mc_cbca)");
+	hipStream_t st = as_stream(stream);
+	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
+	if (rc) return rc;
+	rc = cbca_tiled(scratch, vol_in, vol_out, D, H, W, direction, -1, st);
+	if (rc) return rc;
+	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
 }
 
 size_t mc_sgm2_tmp_bytes(int H, int W, int D)

@@ -44,8 +44,9 @@ int cross(const float *img, float *arms, int H, int W, int L1, float tau1, hipSt
 // ---- cbca v1, adcensus.cu:343-377: one thread per voxel, (D,H,W), reads through L1/L2 -------------
 __global__ void __launch_bounds__(256) cbca_direct_kernel(const float *__restrict__ x0c, const float *__restrict__ x1c,
                                                           const float *__restrict__ vol, float *__restrict__ out, int D, int H, int W,
-                                                          int direction)
+                                                          int direction, const uint32_t *__restrict__ only_if)
 {
+	if (only_if && !*only_if) return;  // standalone fast path handled this call (no arm saturated the packed form)
 	const int x = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
 	const int d = blockIdx.z;
@@ -78,8 +79,298 @@ __global__ void __launch_bounds__(256) cbca_direct_kernel(const float *__restric
 int cbca(const float *x0c, const float *x1c, const float *vin, float *vout, int D, int H, int W, int direction, hipStream_t st)
 {
 	hipLaunchKernelGGL(cbca_direct_kernel, dim3(cdiv(W, 64), cdiv(H, 4), D), dim3(256), 0, st, x0c, x1c, vin, vout, D, H, W,
-	                   direction);
+	                   direction, (const uint32_t *)nullptr);
 	return check_launch("cbca");
+}
+
+
+// =====================================================================================================
+// cbca v2: LDS-staged tiles with packed arm lengths
+// =====================================================================================================
+// The reference's support of voxel (d,y,x) is, in the frame of the reference pixel, simply the per-arm MINIMUM of the
+// two images' arm lengths: with len = |end - coordinate| - 1,
+//   yy in [y - min(U0[y,x], U1[y,xp]), y + min(D0[y,x], D1[y,xp])],  xp = x + d*direction,
+//   xx in [x - min(L0[yy,x], L1[yy,xp]), x + min(R0[yy,x], R1[yy,xp])]
+// (adcensus.cu:359-365: max/min of the exclusive ends, the right image's shifted by -d*direction).  Arm lengths are
+// packed as 4 bytes per pixel (L,R,U,D; saturated at 255) by cbca_pack_kernel.  A block owns a TY x TX pixel tile and
+// ND consecutive disparities: it stages the left image's lengths once, derives the halo the tile actually needs from
+// them (min(l0,l1) <= l0, so the bound holds for every d), and per disparity stages the volume tile (+halo) and the
+// byte-wise minimum with the right image's lengths in LDS; every voxel then runs the reference's loop (rows ascending,
+// x ascending, one fp32 accumulator, IEEE divide: bit-identical), out of LDS wherever the support stays inside the frame.
+
+__global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict__ arms, uint32_t *__restrict__ packed, int H, int W,
+                                                        uint32_t *__restrict__ overflow)
+{
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t HW = (int64_t)H * W;
+	if (id >= HW) return;
+	const int x = (int)(id % W), y = (int)(id / W);
+	const int l = x - (int)arms[0 * HW + id] - 1;
+	const int r = (int)arms[1 * HW + id] - x - 1;
+	const int u = y - (int)arms[2 * HW + id] - 1;
+	const int d = (int)arms[3 * HW + id] - y - 1;
+	auto sat = [](int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+	packed[id] = sat(l) | (sat(r) << 8) | (sat(u) << 16) | (sat(d) << 24);
+	if (overflow && (l > 254 || r > 254 || u > 254 || d > 254)) atomicOr(overflow, 1u);
+}
+
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bytemin4(uint32_t a, uint32_t b)
+{
+	// per-byte unsigned minimum through two packed 16-bit minima (even / odd bytes)
+	const uint32_t ae = a & 0x00ff00ffu, be = b & 0x00ff00ffu;
+	const uint32_t ao = (a >> 8) & 0x00ff00ffu, bo = (b >> 8) & 0x00ff00ffu;
+	const ushort2v me = __builtin_elementwise_min(__builtin_bit_cast(ushort2v, ae), __builtin_bit_cast(ushort2v, be));
+	const ushort2v mo = __builtin_elementwise_min(__builtin_bit_cast(ushort2v, ao), __builtin_bit_cast(ushort2v, bo));
+	return __builtin_bit_cast(uint32_t, me) | (__builtin_bit_cast(uint32_t, mo) << 8);
+}
+
+constexpr int CB_TY = 16;   // output rows per tile
+constexpr int CB_LW = 64;   // staged columns per tile = lanes of a wave
+constexpr int CB_ND = 8;    // disparities per block
+
+struct CbcaArgs {
+	const uint32_t *p0, *p1;      // packed arm lengths (H,W)
+	const float *vin;
+	float *vout;
+	int D, H, W, direction;
+	int nd;                       // disparities per block
+	const uint32_t *overflow;     // optional: set by cbca_pack when an arm saturated the packed form -> do nothing
+	int ablate;                   // tuning aid (MC_CBCA_ABLATE): 1 = skip aggregation, 2 = skip re-staging
+	int gx, gy, gz;               // tile grid
+};
+
+typedef unsigned cb_u32;
+
+// A block owns 16 rows x (64 - 2*HALO) columns of output and `nd` consecutive disparities.  The staged frame is 64
+// columns wide -- lane i of every wave IS staged column i -- and 16 + 2*HALO rows high, so one wave-load stages one row
+// and LDS offsets are `row * 64 + lane` for both the volume tile and the combined (byte-wise minimum) arm lengths.
+// Staging is register-prefetched two disparities ahead and double-buffered in LDS: global loads of d+1 and d+2 are in
+// flight while d is aggregated.  All global accesses are raw-buffer ops on one (H,W) plane with 32-bit offsets.
+// Supports inside the frame -- nearly all, with the reference's tight colour thresholds -- are summed out of LDS; the
+// minimal 3x3 support takes a straight-line path when a whole wave has it; a row or run that leaves the frame is read
+// from global memory instead (same order of additions), so any arm length is handled in the one launch.
+template <int HALO>
+__global__ void __launch_bounds__(256) cbca_tile_kernel(const CbcaArgs A)
+{
+	constexpr int RY = CB_TY + 2 * HALO;       // staged rows (capacity)
+	constexpr int TXO = CB_LW - 2 * HALO;      // output columns per tile
+	constexpr int NR = (RY + 3) / 4;           // staged rows per wave
+	__shared__ cb_u32 P0t[RY * CB_LW];
+	__shared__ cb_u32 Mt[2][RY * CB_LW];
+	__shared__ float Vt[2][RY * CB_LW];
+
+	if (A.overflow && *A.overflow) return;  // block-uniform: the caller's v1 launch handles this call
+	const int H = A.H, W = A.W, D = A.D, direction = A.direction;
+	const int HWi = H * W;                  // < 2^31 / 4 checked by the launcher
+	const int tid = threadIdx.x;
+	const int lx = tid & 63, wv = tid >> 6;
+	// XCD-aware tile order: blocks b, b+8, b+16, ... run on one XCD (own L2).  Give every XCD one contiguous run of
+	// tiles, walked y-fastest, so that tiles sharing halo rows meet in the same L2 close in time.
+	const int gx = A.gx, gy = A.gy;
+	const int ntiles = gx * gy * A.gz;
+	const int b = blockIdx.x;
+	const int per = (ntiles + 7) >> 3;
+	const int t = (b & 7) * per + (b >> 3);
+	if (t >= ntiles) return;
+	const int by = t % gy, bx = (t / gy) % gx, bz = t / (gy * gx);
+	const int x0 = bx * TXO, y0 = by * CB_TY;
+	const int d0 = bz * A.nd;
+	const int d1 = min(D, d0 + A.nd);
+	const int ty_n = min(CB_TY, H - y0);
+	const int ry0 = max(0, y0 - HALO), ry1 = min(H, y0 + CB_TY + HALO);
+	const int hu = y0 - ry0;
+	const int nrows = ry1 - ry0;
+	const int xs = x0 - HALO + lx;          // image column staged by this lane (may lie outside the image)
+	const bool xs_in = xs >= 0 && xs < W;
+	const bool out_lane = lx >= HALO && lx < HALO + TXO && xs < W;  // this lane produces output (xs >= 0 follows)
+	const int plane_bytes = HWi * 4;
+	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)A.p1, 0, plane_bytes, 0x00020000);
+	const cb_u32 OOB = 0x80000000u;         // voffset beyond num_records: load returns 0, store is dropped
+
+	// the left image's lengths, once per block (each wave reads back only rows it wrote itself)
+	{
+		const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)A.p0, 0, plane_bytes, 0x00020000);
+#pragma unroll
+		for (int i = 0; i < NR; ++i) {
+			const int r = wv + 4 * i;
+			if (r < nrows) P0t[r * CB_LW + lx] = __builtin_amdgcn_raw_buffer_load_b32(rp0, xs_in ? (cb_u32)((ry0 + r) * W + xs) * 4u : OOB, 0, 0);
+		}
+	}
+	// byte offsets (within a plane) of this lane's element in each of its staged rows; OOB where there is none
+	cb_u32 voff[NR];
+#pragma unroll
+	for (int i = 0; i < NR; ++i) {
+		const int r = wv + 4 * i;
+		voff[i] = (r < nrows && xs_in) ? (cb_u32)((ry0 + r) * W + xs) * 4u : OOB;
+	}
+
+	struct Stage { cb_u32 pm[NR]; float pv[NR]; };
+	auto fetch = [&](Stage &st, int d) {   // global -> registers
+		const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
+		const int sh = d * direction;
+		const bool pok = xs_in && xs + sh >= 0 && xs + sh < W;
+#pragma unroll
+		for (int i = 0; i < NR; ++i) {
+			st.pv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, voff[i], 0, 0));
+			st.pm[i] = __builtin_amdgcn_raw_buffer_load_b32(rp1, pok ? voff[i] + (cb_u32)(sh * 4) : OOB, 0, 0);
+		}
+	};
+	auto commit = [&](const Stage &st, int buf) {  // registers -> LDS (lengths combined with the left image's)
+#pragma unroll
+		for (int i = 0; i < NR; ++i) {
+			const int r = wv + 4 * i;
+			if (r < nrows) {
+				Mt[buf][r * CB_LW + lx] = bytemin4(P0t[r * CB_LW + lx], st.pm[i]);
+				Vt[buf][r * CB_LW + lx] = st.pv[i];
+			}
+		}
+	};
+
+	Stage sa, sb;
+	fetch(sa, d0);
+	if (d0 + 1 < d1) fetch(sb, d0 + 1);
+	commit(sa, 0);
+	for (int d = d0; d < d1; ++d) {
+		const int buf = A.ablate == 2 ? 0 : ((d - d0) & 1);
+		// sb holds d+1 (in flight or landed); refill sa with d+2
+		if (d + 2 < d1 && A.ablate != 2) fetch(sa, d + 2);
+		__syncthreads();               // buffer `buf` is complete; buffer `buf^1` is no longer being read
+		const cb_u32 *__restrict__ M = Mt[buf];
+		const float *__restrict__ V = Vt[buf];
+		const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
+		const int sh = d * direction;
+		const bool inr = xs + sh >= 0 && xs + sh < W;
+		if (out_lane) {
+#pragma unroll 1
+			for (int i = 0; i < CB_TY / 4; ++i) {
+				const int r = wv + 4 * i;
+				if (r >= ty_n) break;
+				const int o = (r + hu) * CB_LW + lx;           // LDS index of this pixel (same for M and V)
+				const cb_u32 goff = (cb_u32)((y0 + r) * W + xs) * 4u;
+				if (!inr || A.ablate == 1) {  // adcensus.cu:353-354: copied through
+					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(V[o]), ro, goff, 0, 0);
+					continue;
+				}
+				const cb_u32 mc = M[o];
+				// minimal support (every arm 1 pixel: the 3x3 block) for all output lanes of the wave: straight-line
+				const bool c3 = mc == 0x01010101u;  // implies rows y-1, y+1 and columns x-1, x+1 exist and are staged
+				const cb_u32 ma = M[c3 ? o - CB_LW : o] & 0xffffu, mb = M[c3 ? o + CB_LW : o] & 0xffffu;
+				if (__all(c3 && ma == 0x0101u && mb == 0x0101u)) {
+					const float *vc = V + o;
+					float sum = 0;
+					sum += vc[-CB_LW - 1]; sum += vc[-CB_LW]; sum += vc[-CB_LW + 1];
+					sum += vc[-1]; sum += vc[0]; sum += vc[1];
+					sum += vc[CB_LW - 1]; sum += vc[CB_LW]; sum += vc[CB_LW + 1];
+					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum / 9.0f), ro, goff, 0, 0);
+					continue;
+				}
+				const int u = (int)((mc >> 16) & 0xff), dn = (int)(mc >> 24);
+				const int rr = r + hu;
+				float sum = 0;
+				int cnt = 0;
+				int oq = o - u * CB_LW;                         // LDS index of (row q, this column)
+				for (int q = rr - u; q <= rr + dn; ++q, oq += CB_LW) {
+					const bool row_in = q >= 0 && q < nrows;
+					cb_u32 mm;
+					if (row_in) {
+						mm = M[oq];
+					} else {  // row outside the staged frame: lengths from global memory
+						const int g = (ry0 + q) * W + xs;
+						mm = bytemin4(A.p0[g], A.p1[g + sh]);
+					}
+					const int l = (int)(mm & 0xff), rg = (int)((mm >> 8) & 0xff);
+					const int n = l + rg + 1;
+					if (row_in && lx - l >= 0 && lx + rg < CB_LW) {
+						const float *row = V + oq - l;
+						int k = 0;
+						for (; k + 4 <= n; k += 4) {
+							const float v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3];
+							sum += v0; sum += v1; sum += v2; sum += v3;
+						}
+						if (k < n) {
+							const float v0 = row[k];
+							const float v1 = row[min(k + 1, n - 1)], v2 = row[min(k + 2, n - 1)];
+							sum += v0;
+							if (k + 1 < n) sum += v1;
+							if (k + 2 < n) sum += v2;
+						}
+					} else {  // run leaves the frame: from global memory, same order
+						const float *row = A.vin + (size_t)d * HWi + (ry0 + q) * W + xs - l;
+						for (int k = 0; k < n; ++k) sum += row[k];
+					}
+					cnt += n;
+				}
+				__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum / (float)cnt), ro, goff, 0, 0);
+			}
+		}
+		if (d + 1 < d1 && A.ablate != 2) {
+			commit(sb, buf ^ 1);
+			// rotate the register stages: sb <- sa (d+2)
+#pragma unroll
+			for (int i = 0; i < NR; ++i) { sb.pm[i] = sa.pm[i]; sb.pv[i] = sa.pv[i]; }
+		}
+	}
+}
+
+size_t cbca_scratch_bytes(int H, int W) { return ((size_t)2 * H * W * sizeof(uint32_t) + 4 + 255) & ~(size_t)255; }
+
+// scratch = [p0 (H*W) | p1 (H*W) | overflow flag]
+int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st)
+{
+	uint32_t *p0 = (uint32_t *)scratch, *p1 = p0 + (size_t)H * W, *flag = p1 + (size_t)H * W;
+	const int64_t HW = (int64_t)H * W;
+	const hipError_t e = hipMemsetAsync(flag, 0, sizeof(uint32_t), st);
+	if (e != hipSuccess) {
+		set_error("cbca_pack: %s", hipGetErrorString(e));
+		return (int)e;
+	}
+	hipLaunchKernelGGL(cbca_pack_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, x0c, p0, H, W, flag);
+	hipLaunchKernelGGL(cbca_pack_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, x1c, p1, H, W, flag);
+	return check_launch("cbca_pack");
+}
+
+// v1 kernel that runs only when cbca_pack flagged a saturated arm (and the tiled kernel therefore stood down)
+int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
+                     int direction, hipStream_t st)
+{
+	const uint32_t *flag = (const uint32_t *)packed + (size_t)2 * H * W;
+	hipLaunchKernelGGL(cbca_direct_kernel, dim3(cdiv(W, 64), cdiv(H, 4), D), dim3(256), 0, st, x0c, x1c, vin, vout, D, H, W,
+	                   direction, flag);
+	return check_launch("cbca (overflow path)");
+}
+
+// max_arm: largest arm length that can occur (L1-1 when L1 is known, else < 0); picks the staged frame width.
+// Arm lengths saturate at 255 in the packed form: callers route max_arm > 254 to the v1 kernel.
+int cbca_tiled(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm, hipStream_t st)
+{
+	static const int env_nd = [] { const char *e = getenv("MC_CBCA_ND"); return e ? atoi(e) : 0; }();      // tuning aids
+	static const int env_halo = [] { const char *e = getenv("MC_CBCA_HALO"); return e ? atoi(e) : 0; }();
+	CbcaArgs A;
+	A.p0 = (const uint32_t *)packed; A.p1 = A.p0 + (size_t)H * W;
+	A.vin = vin; A.vout = vout;
+	A.D = D; A.H = H; A.W = W; A.direction = direction;
+	A.nd = CB_ND;
+	(void)env_nd;
+	static const int env_abl = [] { const char *e = getenv("MC_CBCA_ABLATE"); return e ? atoi(e) : 0; }();
+	A.ablate = env_abl;
+	A.overflow = max_arm < 0 ? A.p1 + (size_t)H * W : nullptr;  // unknown arm bound: honour cbca_pack's flag
+	// frame width 2 measured best on MI355X for both tight (Middlebury) and looser (KITTI) thresholds; longer arms take
+	// the per-run global path
+	int halo = (max_arm >= 0 && max_arm < 2) ? 1 : 2;
+	if (env_halo > 0) halo = env_halo;
+	if (halo != 1 && halo != 2 && halo != 3 && halo != 4 && halo != 6) halo = 2;
+	A.gx = (int)cdiv(W, CB_LW - 2 * halo); A.gy = (int)cdiv(H, CB_TY); A.gz = (int)cdiv(D, A.nd);
+	const int64_t ntiles = (int64_t)A.gx * A.gy * A.gz;
+	const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8)), block(256);
+	switch (halo) {
+	case 1: hipLaunchKernelGGL(cbca_tile_kernel<1>, grid, block, 0, st, A); break;
+	case 4: hipLaunchKernelGGL(cbca_tile_kernel<4>, grid, block, 0, st, A); break;
+	case 6: hipLaunchKernelGGL(cbca_tile_kernel<6>, grid, block, 0, st, A); break;
+	case 3: hipLaunchKernelGGL(cbca_tile_kernel<3>, grid, block, 0, st, A); break;
+	default: hipLaunchKernelGGL(cbca_tile_kernel<2>, grid, block, 0, st, A); break;
+	}
+	return check_launch("cbca_tiled");
 }
 
 }  // namespace mc

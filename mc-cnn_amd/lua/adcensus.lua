@@ -29,6 +29,9 @@ int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int
 int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream);
 int mc_cross(const float *img, float *arms, int H, int W, int L1, float tau1, void *stream);
 int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction, void *stream);
+size_t mc_cbca_scratch_bytes(int H, int W);
+int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
+               void *scratch, size_t scratch_bytes, void *stream);
 size_t mc_sgm2_tmp_bytes(int H, int W, int D);
 int mc_sgm2(const float *x0, const float *x1, const float *in_hwd, float *out_hwd, void *tmp, size_t tmp_bytes,
             int H, int W, int D, float pi1, float pi2, float tau_so, float alpha1, float sgm_q1, float sgm_q2,
@@ -88,9 +91,15 @@ function adcensus.cross(x0, out, L1, tau1)                   -- adcensus.cu:324-
    check(lib.mc_cross(ptr(x0, 'cross'), ptr(out, 'cross'), out:size(3), out:size(4), L1, tau1, nil), 'cross')
 end
 
-function adcensus.cbca(x0c, x1c, vol_in, vol_out, direction) -- adcensus.cu:379-400
-   check(lib.mc_cbca(ptr(x0c, 'cbca'), ptr(x1c, 'cbca'), ptr(vol_in, 'cbca'), ptr(vol_out, 'cbca'),
-                     vol_out:size(2), vol_out:size(3), vol_out:size(4), direction, nil), 'cbca')
+-- adcensus.cbca, adcensus.cu:379-400, on the LDS-tiled kernel (mc_cbca_ws); the packed arm lengths live in a
+-- scratch CudaTensor this module keeps and grows on demand (same stream, so reuse across calls is ordered).
+local cbca_scratch = torch.CudaTensor()
+function adcensus.cbca(x0c, x1c, vol_in, vol_out, direction)
+   local D, H, W = vol_out:size(2), vol_out:size(3), vol_out:size(4)
+   local need = tonumber(lib.mc_cbca_scratch_bytes(H, W))
+   if cbca_scratch:nElement() * 4 < need then cbca_scratch:resize(math.ceil(need / 4)) end
+   check(lib.mc_cbca_ws(ptr(x0c, 'cbca'), ptr(x1c, 'cbca'), ptr(vol_in, 'cbca'), ptr(vol_out, 'cbca'),
+                        D, H, W, direction, cbca_scratch:data(), cbca_scratch:nElement() * 4, nil), 'cbca')
 end
 
 -- adcensus.sgm2, adcensus.cu:620-697.  `tmp` is the reference's (W,D) line-state tensor; this

@@ -76,7 +76,35 @@ def test_cbca(mc, oracle, H, W, D, L1, tau1, direction):
     want = oracle.cbca(x0c, x1c, vol, direction)
     out = torch.empty((1, D, H, W), device="cuda")
     mc.adcensus.cbca(dev(x0c), dev(x1c), dev(vol), out, direction)
-    assert_same(host(out), want, "cbca")
+    assert_same(host(out), want, "cbca (LDS-tiled, mc_cbca_ws)")
+    out2 = torch.empty((1, D, H, W), device="cuda")
+    mc.adcensus.cbca_reference_shaped(dev(x0c), dev(x1c), dev(vol), out2, direction)
+    assert_same(host(out2), want, "cbca (mc_cbca)")
+
+
+@pytest.mark.parametrize("H,W,D", [(50, 200, 40), (33, 131, 17), (16, 64, 8), (17, 65, 9), (70, 90, 100)])
+@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.02), ("smooth", 14, 0.3), ("blocky", 14, 0.2), ("flat", 13, 1.0),
+                                        ("flat", 30, 1.0), ("blocky", 40, 0.3), ("random", 5, 0.13)])
+@pytest.mark.parametrize("direction", [-1, 1])
+def test_cbca_tiled_shapes(mc, oracle, H, W, D, mk, L1, tau1, direction):
+    """Tile edges (H % 16, W % 64), halos from 1 to the staged capacity, and arms beyond it (in-launch fallback)."""
+    if mk == "smooth":
+        x0, x1 = smooth_pair(H, W, min(D, 8), seed=H)
+    elif mk == "blocky":
+        x0, x1 = blocky_pair(H, W, seed=W)
+    elif mk == "random":
+        x0, x1 = random_pair(H, W, seed=3)
+    else:
+        x0 = np.zeros((H, W), np.float32)
+        x1 = np.zeros((H, W), np.float32)
+        x1[H // 2:, W // 3:] = 2.0  # one edge so that left and right arms differ
+    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
+    vl, vr = raw_volumes(D, H, W, seed=13)
+    vol = vl if direction == -1 else vr
+    want = oracle.cbca(x0c, x1c, vol, direction)
+    out = torch.empty((1, D, H, W), device="cuda")
+    mc.adcensus.cbca(dev(x0c), dev(x1c), dev(vol), out, direction)
+    assert_same(host(out), want, "cbca tiled")
 
 
 SGM_PARAMS = [  # pi1, pi2, tau_so, alpha1, q1, q2
@@ -206,6 +234,21 @@ def test_normalize_fix_border(mc, oracle):
             t = dev(vol)[None].clone()
             mc.adcensus.fix_border(t, n, direction)
             assert_same(host(t), oracle.fix_border(vol, n, direction), "fix_border")
+
+
+def test_cbca_arms_beyond_packed_range(mc, oracle):
+    """Arms longer than 254 pixels saturate the packed byte lengths: the standalone operator must notice and take
+    the float-arm kernel (mc_cbca_ws's overflow flag), still bit-exact."""
+    H, W, D = 3, 700, 3
+    x0 = np.zeros((H, W), np.float32)
+    x1 = np.zeros((H, W), np.float32)
+    x0c, x1c = oracle.cross(x0, 400, 1.0), oracle.cross(x1, 400, 1.0)
+    assert (np.arange(W)[None, :] - x0c[0] - 1).max() > 254
+    vl, _ = raw_volumes(D, H, W, seed=3)
+    want = oracle.cbca(x0c, x1c, vl, -1)
+    out = torch.empty((1, D, H, W), device="cuda")
+    mc.adcensus.cbca(dev(x0c), dev(x1c), dev(vl), out, -1)
+    assert_same(host(out), want, "cbca with arms > 254")
 
 
 PRED_CASES = [
