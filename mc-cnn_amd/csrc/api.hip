@@ -204,7 +204,9 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	const float *cur[2];
 	auto other = [&](int v) -> float * { return cur[v] == bufA[v] ? bufB[v] : bufA[v]; };
 	bool hwd;  // layout of cur[]
-	if (from_feat && p->cbca_i1 == 0 && p->sgm_i > 0) {
+	// the MFMA StereoJoin addresses one image row of a volume and one feature map with 32-bit byte offsets
+	const bool join_fits = (int64_t)W * ((D + 3) / 4 * 4) * 4 < ((int64_t)1 << 31) && ((int64_t)C * HW + W) * 4 < ((int64_t)1 << 31);
+	if (from_feat && p->cbca_i1 == 0 && p->sgm_i > 0 && join_fits) {
 		// fast path: StereoJoin straight into (H,W,ds) with NaN fill and fix_border folded in
 		RUN(stereo_join_hwd(featL, featR, bufA[0], bufA[1], C, D, ds, H, W, p->border_n, st));
 		cur[0] = bufA[0]; cur[1] = bufA[1];

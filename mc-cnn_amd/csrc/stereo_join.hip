@@ -38,22 +38,25 @@ int stereo_join_dhw(const float *fL, const float *fR, float *volL, float *volR, 
 // fmaf chain), so chaining the k-steps with c ascending reproduces StereoJoin_'s
 // `sum -= L*R` (adcensus.cu:1468-1471) bit for bit -- checked by tests/test_gpu_parity.py.
 //
-// One wave owns 32 consecutive OUTPUT pixels of one volume (the M side, operand A, negated
-// features held in VGPRs for the whole band) and walks the partner tiles of 32 pixels (N side,
-// operand B) that cover disparities 0..D-1.  The two volumes use opposite orientations so that
-// for either one a single accumulator register is, across lanes, a run of consecutive d of ONE
-// pixel, i.e. a contiguous 128-byte store into the (H,W,ds) volume:
-//   SIDE 0 (left  volume): M <-> x  (A = -L), N <-> x' (B = R), d = x - x' = m - n + 32*J
-//   SIDE 1 (right volume): M <-> x' (A = -R), N <-> x  (B = L), d = x - x' = n - m + 32*J
-// Every (pixel, d < D) voxel is written exactly once: NaN where the partner pixel is outside the
-// image (the reference's fill(0/0), main.lua:946).  fix_border is a separate small copy.
+// One wave owns 32 consecutive LEFT pixels x of one image row (M side, operand A = -L, held in VGPRs for
+// the whole band) and walks the right-image tiles x' = p0 - 32J .. (N side, operand B = R, prefetched one
+// tile ahead so its latency hides under the 32 chained MFMAs of the current tile).  Every 32x32 tile is
+// computed ONCE and stored twice:
+//   left  volume: a register across lanes 0..31 is pixel x = p0+m, disparities d = m - n + 32J descending
+//                 with the lane -> one 128-byte run of the (H,W,ds) volume;
+//   right volume: the tile goes through a padded LDS transpose so that a register across lanes is pixel
+//                 x' = q0+n with d ascending with the lane -> again one 128-byte run.
+// Every (pixel, d < D) voxel of both volumes is written exactly once, NaN where the partner pixel lies
+// outside the image (the reference's fill(0/0), main.lua:946): "virtual" tiles p0 >= W exist only to write
+// the right volume's NaN triangle.  fix_border is a separate small copy.
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-template <int SIDE, int KSTEPS>  // KSTEPS = ceil(C/2) rounded up to a supported size
+template <int KSTEPS>  // KSTEPS = ceil(C/2) rounded up to a supported size
 __global__ void __launch_bounds__(256) join_mfma_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
-                                                        float *__restrict__ vol, int C, int D, int ds, int H, int W,
-                                                        int tiles_per_row)
+                                                        float *__restrict__ volL, float *__restrict__ volR, int C, int D,
+                                                        int ds, int H, int W, int tiles_per_row)
 {
+	__shared__ float T[4][32 * 33];
 	const int lane = threadIdx.x & 63;
 	const int wid = threadIdx.x >> 6;
 	// XCD-aware mapping: blocks b and b+8k share an XCD (b % 8); give all blocks of one image
@@ -66,51 +69,107 @@ __global__ void __launch_bounds__(256) join_mfma_kernel(const float *__restrict_
 	if (y >= H || tile >= tiles_per_row) return;
 
 	const int64_t HW = (int64_t)H * W;
-	const float *__restrict__ fA = (SIDE == 0 ? fL : fR) + (int64_t)y * W;
-	const float *__restrict__ fB = (SIDE == 0 ? fR : fL) + (int64_t)y * W;
+	const float *__restrict__ fA = fL + (int64_t)y * W;
+	const float *__restrict__ fB = fR + (int64_t)y * W;
 	const int p0 = tile * 32;
 	const int nl = lane & 31, kh = lane >> 5;
+	const bool real_tile = p0 < W;  // wave-uniform; virtual tiles only fill the right volume's NaN triangle
+	float *Tw = T[wid];
 
-	// A operand: -feat[c = 2kk + kh][p0 + nl], zero outside the image / channel range
+	// Features of this image row as raw buffers: (C,H,W) plane stride HW, so channel c of pixel x is at byte
+	// ((c*HW) + x)*4 from the row's first pixel.  The lane part (pixel, channel parity) is the 32-bit voffset, the
+	// channel-pair part 2*kk*HW*4 a scalar soffset; out-of-range lanes get an offset beyond the buffer -> 0.0.
+	const unsigned feat_bytes = (unsigned)(((int64_t)(C - 1) * HW + W) * 4);  // < 2^31 checked by the launcher
+	const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)fA, 0, feat_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)fB, 0, feat_bytes, 0x00020000);
+	const unsigned pair_bytes = (unsigned)(2 * HW * 4);
+	const unsigned OOBF = 0x80000000u;
+	// A operand: -L[c = 2kk + kh][p0 + nl], zero outside the image / channel range
 	float a[KSTEPS];
 	{
 		const int px = p0 + nl;
+		const unsigned vo = (real_tile && px < W) ? (unsigned)((int64_t)kh * HW + px) * 4u : OOBF;
 #pragma unroll
 		for (int kk = 0; kk < KSTEPS; ++kk) {
 			const int c = 2 * kk + kh;
-			a[kk] = (px < W && c < C) ? -fA[c * HW + px] : 0.0f;
+			const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, c < C ? vo : OOBF, kk * pair_bytes, 0));
+			a[kk] = -v;  // out-of-range loads return +0.0 -> -0.0: fma(-0.0, b, acc) == acc exactly as fma(0.0, b, acc)
 		}
 	}
 	const float NANV = __builtin_nanf("");
 	const int nJ = (D + 30) / 32 + 1;  // tiles J = 0..nJ-1 cover d up to 32*(nJ-1)+31 >= D-1
+
+	auto load_b = [&](float (&bv)[KSTEPS], int J) {
+		const int qx = p0 - 32 * J + nl;
+		const bool qin = real_tile && qx >= 0 && qx < W;
+		const unsigned vo = qin ? (unsigned)((int64_t)kh * HW + qx) * 4u : OOBF;
+#pragma unroll
+		for (int kk = 0; kk < KSTEPS; ++kk) {
+			const int c = 2 * kk + kh;
+			bv[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rB, c < C ? vo : OOBF, kk * pair_bytes, 0));
+		}
+	};
+
+	const int row_bytes = W * ds * 4;  // one image row of a (H,W,ds) volume; < 2^31 checked by the launcher
+	const __amdgpu_buffer_rsrc_t rowL = __builtin_amdgcn_make_buffer_rsrc((void *)(volL + (int64_t)y * W * ds), 0, row_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rowR = __builtin_amdgcn_make_buffer_rsrc((void *)(volR + (int64_t)y * W * ds), 0, row_bytes, 0x00020000);
+
+	float bcur[KSTEPS], bnxt[KSTEPS];
+	load_b(bcur, 0);
 	for (int J = 0; J < nJ; ++J) {
-		const int q0 = SIDE == 0 ? p0 - 32 * J : p0 + 32 * J;  // partner tile base
+		const int q0 = p0 - 32 * J;  // partner tile base (right-image pixels x')
+		if (J + 1 < nJ) load_b(bnxt, J + 1);
 		floatx16 acc;
 #pragma unroll
 		for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-		const bool any_in = (q0 + 31 >= 0) && (q0 < W);  // wave-uniform
-		if (any_in) {
-			const int qx = q0 + nl;
-			const bool qin = qx >= 0 && qx < W;
-			float bv[KSTEPS];
+		if (real_tile && q0 + 31 >= 0) {  // wave-uniform: skip tiles entirely left of the image (they store NaN)
 #pragma unroll
-			for (int kk = 0; kk < KSTEPS; ++kk) {
-				const int c = 2 * kk + kh;
-				bv[kk] = (qin && c < C) ? fB[c * HW + qx] : 0.0f;
-			}
-#pragma unroll
-			for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bv[kk], acc, 0, 0, 0);
+			for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bcur[kk], acc, 0, 0, 0);
 		}
 		// C/D layout: col n = lane & 31, row m = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
-		const int qn = q0 + nl;  // partner pixel of this lane's column
+		// Stores are raw-buffer ops on this image row of the volume (32-bit offsets; an offset beyond the row's bytes
+		// drops the lane), so no 64-bit address arithmetic or exec-mask branches per element.
+		const int qn = q0 + nl;  // right-image pixel of this lane's column
 		const bool qok = qn >= 0 && qn < W;
+		if (real_tile) {
+			// element (m, n): pixel x = p0+m, d = m - nl + 32J  ->  float offset (p0+m)*ds + d
+			const int dJ = 32 * J - nl;
+			int off = (p0 + 4 * kh) * ds + 4 * kh + dJ;  // m = 4*kh
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int m = (i & 3) + 8 * (i >> 2) + 4 * kh;
+				const int d = m + dJ;
+				const bool ok = p0 + m < W && d >= 0 && d < D;
+				const int mo = (i & 3) + 8 * (i >> 2);  // compile-time part of m
+				__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qok ? acc[i] : NANV), rowL,
+				                                      ok ? (unsigned)(off + mo * (ds + 1)) * 4u : 0x80000000u, 0, 0);
+			}
+		}
+		// right volume: transpose through LDS (row stride 33: conflict-free both ways)
 #pragma unroll
 		for (int i = 0; i < 16; ++i) {
 			const int m = (i & 3) + 8 * (i >> 2) + 4 * kh;
-			const int px = p0 + m;
-			const int d = SIDE == 0 ? m - nl + 32 * J : nl - m + 32 * J;
-			if (px < W && d >= 0 && d < D) vol[((int64_t)y * W + px) * ds + d] = qok ? acc[i] : NANV;
+			Tw[m * 33 + nl] = acc[i];
 		}
+		// (one wave owns Tw: LDS ops of a wave complete in order, no barrier needed)
+		{
+			const int mL = nl;                 // lane <-> left pixel offset m
+			const bool pin = p0 + mL < W;      // the left pixel x = p0 + m exists
+			// element (m = mL, n): pixel x' = q0+n, d = mL - n + 32J  ->  float offset (q0+n)*ds + d
+			const int offR = (q0 + kh) * ds + mL - kh + 32 * J;   // n = kh
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int n = 2 * i + kh;      // right pixel offset handled by this half-wave in this step
+				const int xr = q0 + n;
+				const int d = mL - n + 32 * J;
+				const bool ok = xr >= 0 && xr < W && d >= 0 && d < D;
+				const float v = Tw[mL * 33 + n];
+				__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pin ? v : NANV), rowR,
+				                                      ok ? (unsigned)(offR + 2 * i * (ds - 1)) * 4u : 0x80000000u, 0, 0);
+			}
+		}
+#pragma unroll
+		for (int kk = 0; kk < KSTEPS; ++kk) bcur[kk] = bnxt[kk];
 	}
 }
 
@@ -133,15 +192,14 @@ __global__ void __launch_bounds__(256) fix_border_hwd_kernel(float *__restrict__
 int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int ds, int H, int W, int n,
                     hipStream_t st)
 {
-	const int tiles = (W + 31) / 32;
+	const int tiles = (W + D - 1 + 31) / 32;  // incl. the virtual tiles right of the image (right volume's NaN triangle)
 	const int blocks_per_row = (tiles + 3) / 4;
 	const int rows8 = (H + 7) / 8;
 	const dim3 grid((unsigned)(rows8 * blocks_per_row * 8)), block(256);
 	const int ks = (C + 1) / 2;
 #define MC_JOIN_LAUNCH(KS)                                                                                                  \
 	do {                                                                                                                    \
-		hipLaunchKernelGGL((join_mfma_kernel<0, KS>), grid, block, 0, st, fL, fR, volL, C, D, ds, H, W, tiles);              \
-		hipLaunchKernelGGL((join_mfma_kernel<1, KS>), grid, block, 0, st, fL, fR, volR, C, D, ds, H, W, tiles);              \
+		hipLaunchKernelGGL((join_mfma_kernel<KS>), grid, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles);             \
 	} while (0)
 	if (ks <= 8) MC_JOIN_LAUNCH(8);
 	else if (ks <= 16) MC_JOIN_LAUNCH(16);
