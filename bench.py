@@ -96,6 +96,30 @@ def cpu_baseline(cfg, host, budget_rows):
                        (rows, W, D, rows, H, dt))
 
 
+def reference_on_gpu(cfg, xb, kw, prm, D):
+    """The reference's OWN kernels (oracle/_ref: /root/reference/adcensus.cu compiled for gfx950, test
+    infrastructure) driven through main.lua's stereo_predict sequence on the same inputs and the same GPU:
+    one warm-up + one timed run.  Reported beside the product's number, never part of it."""
+    import torch
+    try:
+        from oracle.ref_lib import RefLib, RefUnavailable
+        from ref_pipeline import ref_stereo_predict
+        ref = RefLib()
+    except Exception as e:  # not built (needs /root/reference at build time)
+        return dict(available=False, reason=str(e)[:120])
+    preset, H, W, _, C, _ = cfg
+    args = dict(feat=kw["feat"]) if C else dict(raw=kw["raw"])
+    ref_stereo_predict(ref, prm, xb, D, **args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ref_stereo_predict(ref, prm, xb, D, **args)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(available=True, ms_per_pair=round(dt * 1e3, 2), value=round(2.0 * H * W * D / 1e6 / dt, 1),
+                unit="MPix-disp/s", kind="reference kernels (hipcc build of adcensus.cu) + torch glue, same MI355X",
+                note="2W+2H sgm2 launches per volume as in adcensus.cu:639-693; includes host launch overhead")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +128,7 @@ def main():
     ap.add_argument("--config", default="kitti_fast", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline band (0 = auto)")
+    ap.add_argument("--no-ref-gpu", action="store_true", help="skip timing the reference's own kernels on this GPU")
     args = ap.parse_args()
 
     import torch
@@ -170,14 +195,14 @@ def main():
         stage = {k: round(v, 4) for k, v in acc.items() if k != "_"}
         ab = algorithmic_bytes(prm, H, W, D, C)
         dom = "cbca" if ab["cbca"] > ab["sgm"] else "sgm"
-        n_launch = {"sgm": 4 * prm["sgm_i"], "cbca": 2 * (prm["cbca_i1"] + prm["cbca_i2"])}[dom]
+        n_launch = {"sgm": 3 * prm["sgm_i"], "cbca": 2 * (prm["cbca_i1"] + prm["cbca_i2"])}[dom]
         achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9 if acc[dom] > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(dom)
-        roof = dict(bound="hbm", kernel={"sgm": "sgm_pass_kernel (4 direction sweeps over both volumes)",
-                                         "cbca": "cbca kernel (one launch per iteration per volume)"}[dom],
+        roof = dict(bound="hbm", kernel={"sgm": "sgm_pass_kernel (right+left sweep, down sweep, up sweep: 3 launches over both volumes)",
+                                         "cbca": "cbca_tile_kernel (one launch per iteration per volume)"}[dom],
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=traffic, launches_per_step=n_launch,
                     algorithmic_bytes_per_launch=round(ab[dom] / n_launch),
@@ -189,16 +214,20 @@ def main():
         rows = args.cpu_rows or {"kitti_fast": 370, "kitti_slow": 370, "mb_slow": 8, "tiny": 48}[args.config]
         cpu = cpu_baseline(cfg, host, rows)
 
+    refgpu = None
+    if rank == 0 and world == 1 and not args.no_ref_gpu and args.config in ("kitti_fast", "kitti_slow", "tiny"):
+        refgpu = reference_on_gpu(cfg, xb, kw, prm, D)
+
     if rank == 0:
         line = {
-            "metric": "Mega-pixel-disparities/sec (cost-vol+CBCA+SGM+post, end-to-end disp)",
+            "metric": "Mega-pixel-disparities/sec (cost-vol+CBCA+SGM) + end-to-end disp ms/pair",
             "value": round(value, 1), "unit": "MPix-disp/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg_name, "H": H, "W": W, "disp_max": D, "feature_channels": C,
                        "params": preset_name, "pairs_per_step": world, "parallelism": "one pair per GPU",
                        "end_to_end_ms_per_pair": round(ms_per_step, 4)},
-            "stage_ms": stage, "roofline": roof, "cpu_baseline": cpu,
+            "stage_ms": stage, "roofline": roof, "cpu_baseline": cpu, "reference_on_gpu": refgpu,
         }
         print(json.dumps(line))
     if world > 1:

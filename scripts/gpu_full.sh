@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage (on the GPU box via gpurun): bash scripts/gpu_full.sh <tag>
+# Everything the round's evidence needs: -m gpu tests, smoke, bench lines (3 configs, with CPU baseline and the
+# reference-on-GPU leg), rocprofv3 kernel stats, PMC traffic passes.
+TAG=${1:-full}
+O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
+nproc > $O/nproc.txt
+timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+timeout 400 python bench.py --steps 30 --warmup 3 > $O/bench_kitti_fast.json 2> $O/bench_kitti_fast.err
+timeout 400 python bench.py --config kitti_slow --steps 20 --warmup 3 > $O/bench_kitti_slow.json 2> $O/bench_kitti_slow.err
+timeout 400 python bench.py --config mb_slow --steps 5 --warmup 1 > $O/bench_mb_slow.json 2> $O/bench_mb_slow.err
+for c in kitti_fast kitti_slow mb_slow; do python -c "
+import json; j=json.load(open('$O/bench_$c.json')); print('$c', j['value'], j['ms_per_step'], j['stage_ms'], j['roofline']['frac'], (j.get('reference_on_gpu') or {}).get('ms_per_pair'), j['cpu_baseline']['value'] if j.get('cpu_baseline') else None)"; done
+bash scripts/gpu_prof.sh $TAG kitti_fast 10 > /dev/null
+bash scripts/gpu_prof.sh $TAG kitti_slow 5 > /dev/null
+bash scripts/gpu_prof.sh $TAG mb_slow 2 > /dev/null
+bash scripts/gpu_pmc.sh $TAG kitti_fast 3 > /dev/null
+bash scripts/gpu_pmc.sh $TAG mb_slow 1 > /dev/null
+ls $O

@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""profiles/traffic_<config>.json from the PMC passes of scripts/gpu_pmc.sh: measured HBM-side bytes per LAUNCH of the
+dominant kernel groups (`sgm`: the sgm_pass_kernel launches of one step; `cbca`: cbca_tile_kernel), collected and
+corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes, FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE x2 on
+gfx950 (128-byte requests tallied as 64 B), WRITE_SIZE at face value.
+  python scripts/make_traffic_json.py gpurun_out/<tag>/pmc_<config> <config>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main(d, config):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob(os.path.join(d, "p*", "*_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean over dispatches; source: " + d}
+    groups = {"sgm": "sgm_pass_kernel", "cbca": "cbca_tile_kernel", "join": "join_mfma_kernel", "transpose": "transpose_kernel"}
+    for g, pat in groups.items():
+        ks = [k for k in acc if pat in k]
+        if not ks:
+            continue
+        tot, per_kernel = 0.0, {}
+        for k in ks:
+            rd = 2 * sum(acc[k]["FETCH_SIZE"]) / max(1, len(acc[k]["FETCH_SIZE"])) * 1024
+            wr = sum(acc[k]["WRITE_SIZE"]) / max(1, len(acc[k]["WRITE_SIZE"])) * 1024
+            per_kernel[k[:90]] = dict(read=round(rd), write=round(wr))
+            tot += rd + wr
+        out[g] = round(tot / len(ks))
+        out[g + "_kernels"] = per_kernel
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_%s.json" % config)
+    json.dump(out, open(path, "w"), indent=1)
+    print(path, {k: v for k, v in out.items() if not k.endswith("_kernels") and k != "_note"})
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
