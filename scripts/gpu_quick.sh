@@ -6,7 +6,7 @@ timeout 900 python -m pytest tests -m gpu -x -q "$@" > $O/pytest_gpu.log 2>&1; e
 tail -4 $O/pytest_gpu.log
 for cfg in kitti_fast kitti_slow mb_slow; do
   steps=20; [ $cfg = mb_slow ] && steps=3
-  timeout 300 python bench.py --config $cfg --steps $steps --warmup 2 --no-cpu-baseline > $O/bench_$cfg.json 2> $O/bench_$cfg.err
+  timeout 300 python bench.py --config $cfg --steps $steps --warmup 2 --no-cpu-baseline --no-ref-gpu > $O/bench_$cfg.json 2> $O/bench_$cfg.err
   python - <<PY
 import json
 try:
