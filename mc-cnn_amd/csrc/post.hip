@@ -294,8 +294,46 @@ int subpixel(const float *d0, const float *vol, float *out, int D, int H, int W,
 }
 
 // ---- median2d, adcensus.cu:1575-1594 ------------------------------------------------------------
-// xs[n/2] of the ascending sort of the in-bounds taps: computed by rank counting (no NaNs
-// reach this stage, so any correct selection equals the reference's selection sort).
+// xs[n/2] of the ascending sort of the in-bounds taps (no NaNs reach this stage, so any correct selection equals
+// the reference's selection sort).  Interior pixels of the 3x3 / 5x5 filters use forgetful selection in registers
+// (repeatedly drop the minimum and maximum of a working set of N/2+2 values, feeding in the rest: ~130 compare-
+// exchanges for N = 25); border pixels and larger kernels count ranks.
+__device__ __forceinline__ void cswap(float &a, float &b)
+{
+	const float lo = fminf(a, b), hi = fmaxf(a, b);
+	a = lo;
+	b = hi;
+}
+
+template <int N>
+__device__ __forceinline__ float median_forgetful(const float (&v)[N])
+{
+	constexpr int M0 = N / 2 + 2;
+	float w[M0];
+#pragma unroll
+	for (int i = 0; i < M0; ++i) w[i] = v[i];
+	int next = M0;
+#pragma unroll
+	for (int m = M0; m > 3; --m) {
+		// minimum of w[0..m) to w[0], maximum to w[m-1]
+#pragma unroll
+		for (int i = 0; i < m / 2; ++i) cswap(w[i], w[m - 1 - i]);
+#pragma unroll
+		for (int i = 1; i < (m + 1) / 2; ++i) cswap(w[0], w[i]);
+#pragma unroll
+		for (int i = m / 2; i < m - 1; ++i) cswap(w[i], w[m - 1]);
+		// forget both; the next unseen value takes the minimum's slot, the set shrinks by one from the top
+		// (N - M0 == M0 - 3 for odd N: every round has a value to feed in)
+		w[0] = v[next < N ? next : N - 1];
+		++next;
+	}
+	// three values left: ranks N/2-1 .. N/2+1
+	cswap(w[0], w[1]);
+	cswap(w[1], w[2]);
+	cswap(w[0], w[1]);
+	return w[1];
+}
+
 template <int KR>
 __global__ void __launch_bounds__(256) median_kernel(const float *__restrict__ img, float *__restrict__ out, int H, int W)
 {
@@ -314,6 +352,15 @@ __global__ void __launch_bounds__(256) median_kernel(const float *__restrict__ i
 	if (x >= W || y >= H) return;
 	const int xa = max(0, x - KR), xb = min(W - 1, x + KR), ya = max(0, y - KR), yb = min(H - 1, y + KR);
 	const int n = (xb - xa + 1) * (yb - ya + 1);
+	if constexpr (KR == 1 || KR == 2) {
+		if (n == K * K) {  // interior pixel
+			float v[K * K];
+#pragma unroll
+			for (int i = 0; i < K * K; ++i) v[i] = tile[ly + i % K][lx + i / K];
+			out[(int64_t)y * W + x] = median_forgetful<K * K>(v);
+			return;
+		}
+	}
 	const int want = n / 2;
 	float res = 0;
 	for (int i = 0; i < K * K; ++i) {
@@ -351,49 +398,78 @@ int median2d(const float *img, float *out, int H, int W, int k, hipStream_t st)
 }
 
 // ---- mean2d, adcensus.cu:1241-1261 ----------------------------------------------------------------
-// Range-gated Gaussian mean.  Tap order (xx outer, yy inner, running kernel index) and the
-// FMA-contracted `sum += img*k` are the reference's, so the result is bit-identical.
-// 64x8 output tile + halo staged in LDS; the (ks,ks) kernel is read through the scalar cache.
-__global__ void __launch_bounds__(256) mean2d_kernel(const float *__restrict__ img, const float *__restrict__ kernel,
-                                                     float *__restrict__ out, int H, int W, int kr, float alpha2)
+// Range-gated Gaussian mean.  Tap order (xx outer, yy inner, running kernel index) and the FMA-contracted
+// `sum += img*k` are the reference's, so the result is bit-identical.
+// A 128-thread block produces a 64 x 8 output tile; a thread owns 4 vertically adjacent outputs, so one LDS read of
+// a tap column feeds up to 4 outputs (their windows overlap in all but 3 rows).  Image tile (+halo) and the (ks,ks)
+// weights live in LDS.  A tap that does not count adds w' = -0.0 instead of branching: x + (-0.0) == x and
+// fma(v, -0.0, s) == s for every finite v and every s this loop can hold (s starts at +0), so gated-out and
+// out-of-image taps (staged as a huge finite value) are exact no-ops.
+constexpr int M2_OY = 4;   // outputs per thread
+constexpr int M2_TR = 2;   // thread rows per block
+__global__ void __launch_bounds__(64 * M2_TR) mean2d_kernel(const float *__restrict__ img, const float *__restrict__ kernel,
+                                                            float *__restrict__ out, int H, int W, int kr, float alpha2)
 {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
-	const int TW = 64 + 2 * kr, TH = 4 + 2 * kr;
+	constexpr int NT = 64 * M2_TR;
+	const int ks = 2 * kr + 1;
+	const int TW = 64 + 2 * kr, TH = M2_TR * M2_OY + 2 * kr;
 	const int TS = TW + 1;
-	const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
-	const float NANV = __builtin_nanf("");
-	for (int i = threadIdx.x; i < TH * TW; i += 256) {
+	const int WS = ks + 2 * (M2_OY - 1);       // padded weight column: [ -3 .. ks+2 ]
+	float *tile = smem;                          // [TH][TS]
+	float *wts = smem + TH * TS;                 // [ks][WS], wts[ix*WS + (M2_OY-1) + iy]
+	const int bx = blockIdx.x * 64, by = blockIdx.y * (M2_TR * M2_OY);
+	const float FAR = 1e30f;                     // |FAR - c| < alpha2 is false for any disparity c
+	for (int i = threadIdx.x; i < TH * TW; i += NT) {
 		const int ty = i / TW, tx = i - ty * TW;
 		const int gx = bx + tx - kr, gy = by + ty - kr;
-		// out-of-image taps become NaN: |NaN - c| < alpha2 is false, same effect as the bounds test
-		smem[ty * TS + tx] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(int64_t)gy * W + gx] : NANV;
+		tile[ty * TS + tx] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(int64_t)gy * W + gx] : FAR;
+	}
+	for (int i = threadIdx.x; i < ks * WS; i += NT) {
+		const int ix = i / WS, j = i - ix * WS - (M2_OY - 1);
+		wts[i] = (j >= 0 && j < ks) ? kernel[ix * ks + j] : -0.0f;
 	}
 	__syncthreads();
 	const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-	const int x = bx + lx, y = by + ly;
-	if (x >= W || y >= H) return;
-	const float c = smem[(ly + kr) * TS + lx + kr];
-	float sum = 0, cnt = 0;
-	const int ks = 2 * kr + 1;
+	const int x = bx + lx, yb = by + ly * M2_OY;
+	if (x >= W || yb >= H) return;
+	float c[M2_OY], sum[M2_OY], cnt[M2_OY];
+#pragma unroll
+	for (int o = 0; o < M2_OY; ++o) {
+		c[o] = tile[(ly * M2_OY + o + kr) * TS + lx + kr];
+		sum[o] = 0.0f;
+		cnt[o] = 0.0f;
+	}
+	const int nj = ks + M2_OY - 1;  // tile rows a thread's 4 windows span
 	for (int ix = 0; ix < ks; ++ix) {
-		const float *col = smem + ly * TS + lx + ix;
-		const float *kcol = kernel + ix * ks;
-		for (int iy = 0; iy < ks; ++iy) {
-			const float v = col[iy * TS];
-			const float w = kcol[iy];
-			if (fabsf(v - c) < alpha2) {
-				sum = fmaf(v, w, sum);
-				cnt += w;
+		const float *col = tile + (ly * M2_OY) * TS + lx + ix;
+		const float *wc = wts + ix * WS + (M2_OY - 1);
+		float w1 = -0.0f, w2 = -0.0f, w3 = -0.0f;  // weights of taps j-1, j-2, j-3
+#pragma unroll 4
+		for (int j = 0; j < nj; ++j) {
+			const float v = col[0];
+			col += TS;
+			const float w0 = wc[j];                  // -0.0 beyond the kernel
+			const float ws[M2_OY] = {w0, w1, w2, w3};  // output o sees this row as its tap j-o
+#pragma unroll
+			for (int o = 0; o < M2_OY; ++o) {
+				const float w = fabsf(v - c[o]) < alpha2 ? ws[o] : -0.0f;
+				sum[o] = fmaf(v, w, sum[o]);
+				cnt[o] += w;
 			}
+			w3 = w2; w2 = w1; w1 = w0;
 		}
 	}
-	out[(int64_t)y * W + x] = sum / cnt;
+#pragma unroll
+	for (int o = 0; o < M2_OY; ++o)
+		if (yb + o < H) out[(int64_t)(yb + o) * W + x] = sum[o] / cnt[o];
 }
 
 int mean2d(const float *img, const float *kernel, float *out, int H, int W, int ks, float alpha2, hipStream_t st)
 {
 	const int kr = ks / 2;
-	const size_t lds = (size_t)(4 + 2 * kr) * (64 + 2 * kr + 1) * sizeof(float);
+	const size_t lds =
+	    ((size_t)(M2_TR * M2_OY + 2 * kr) * (64 + 2 * kr + 1) + (size_t)ks * (ks + 2 * (M2_OY - 1))) * sizeof(float);
 	if (lds > 160 * 1024) {
 		set_error("mean2d: kernel size %d needs %zu B of LDS (> 160 KiB)", ks, lds);
 		return MC_EINVAL;
@@ -405,7 +481,8 @@ int mean2d(const float *img, const float *kernel, float *out, int H, int W, int 
 			return (int)e;
 		}
 	}
-	hipLaunchKernelGGL(mean2d_kernel, dim3(cdiv(W, 64), cdiv(H, 4)), dim3(256), lds, st, img, kernel, out, H, W, kr, alpha2);
+	hipLaunchKernelGGL(mean2d_kernel, dim3(cdiv(W, 64), cdiv(H, M2_TR * M2_OY)), dim3(64 * M2_TR), lds, st, img, kernel, out, H, W, kr,
+	                   alpha2);
 	return check_launch("mean2d");
 }
 
