@@ -42,13 +42,6 @@ int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2
                const int direction[2], int nvol, int H, int W, int D, int ds, const void *maps, float pi1, float pi2,
                float alpha1, float q1, float q2, bool fused, hipStream_t st);
 
-size_t sgm_fused_scratch_bytes(int nvol, int H, int W, int ds);
-int sgm_fused(const float *const C[2], float *const out[2], float *const out2[2], float *const disp[2], const int direction[2],
-              int nvol, int H, int W, int D, int ds, const void *maps, void *scratch, float pi1, float pi2, float alpha1, float q1,
-              float q2, hipStream_t st);
-int sgm_fused_clear_error(void *scratch, int nvol, int H, int W, int ds, hipStream_t st);
-int sgm_fused_guard(const void *scratch, int nvol, int H, int W, int ds, float *disp_out, hipStream_t st);
-
 static thread_local char g_err[512] = "";
 
 void set_error(const char *fmt, ...)
@@ -99,7 +92,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 struct Plan {
 	int Dp;                 // padded pixel stride of the (H,W,Dp) volumes
-	size_t maps, arms, pack, vol, img, gk, sgf;
+	size_t maps, arms, pack, vol, img, gk;
 	size_t total;
 };
 
@@ -116,8 +109,7 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	const int kr = (int)ceil(p->blur_sigma * 3);
 	const int ks = 2 * kr + 1;
 	pl.gk = align_up((size_t)ks * ks * sizeof(float), 256);
-	pl.sgf = sgm_fused_scratch_bytes(2, H, W, pl.Dp);
-	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk + pl.sgf;
+	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk;
 	return pl;
 }
 
@@ -186,10 +178,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	bufC[1] = (float *)w; w += pl.vol;
 	float *img[6];
 	for (int i = 0; i < 6; ++i) { img[i] = (float *)w; w += pl.img; }
-	float *gk = (float *)w; w += pl.gk;
-	void *sgf = w;
-	bool sgf_used = false;
-	if (p->sgm_i > 0) { const int rc0 = sgm_fused_clear_error(sgf, 2, H, W, pl.Dp, st); if (rc0) return rc0; }
+	float *gk = (float *)w;
 	const int Dp = pl.Dp;
 	int rc;
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
@@ -266,15 +255,8 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 			const float *Cv[2] = {cur[0], cur[1]};
 			float *outv[2] = {other(0), other(1)};
 			const bool am = (it == p->sgm_i - 1) && p->cbca_i2 == 0;
-			rc = sgm_fused(Cv, outv, bufC, am ? dispv : nullptr, direction, 2, H, W, D, ds, maps, sgf, p->pi1, p->pi2, p->alpha1,
-			               p->sgm_q1, p->sgm_q2, st);
-			if (rc > 0) return rc;
-			if (rc == 0) {
-				sgf_used = true;
-			} else {
-				RUN(sgm_sweeps(Cv, outv, bufC, am ? dispv : nullptr, direction, 2, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
-				               p->sgm_q1, p->sgm_q2, true, st));
-			}
+			RUN(sgm_sweeps(Cv, outv, bufC, am ? dispv : nullptr, direction, 2, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
+			               p->sgm_q1, p->sgm_q2, true, st));
 			have_disp = am;
 			cur[0] = outv[0]; cur[1] = outv[1];
 		}
@@ -345,7 +327,6 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		}
 		RUN(mean2d(t2, gk, disp_out, H, W, ks, p->blur_t, st));
 	}
-	if (sgf_used) RUN(sgm_fused_guard(sgf, 2, H, W, ds, disp_out, st));
 	tm.mark(ST_POST);
 #undef RUN
 	return 0;
