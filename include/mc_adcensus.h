@@ -37,7 +37,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define MC_ABI_VERSION 1
+#define MC_ABI_VERSION 2
 #define MC_EINVAL (-22)
 #define MC_SGM_MAX_D 512   /* reference: __shared__ float[400], adcensus.cu:574 */
 #define MC_JOIN_MAX_C 128  /* reference: float L_cache[128], adcensus.cu:1460-1461 */
@@ -174,7 +174,16 @@ typedef struct mc_params {
 	int lr_check;      /* 1 = kitti/kitti2015 branch main.lua:1054-1066, 0 = mb */
 	int border_n;      /* fix_border n = (get_window_size(net)-1)/2, main.lua:923 */
 	int median_k;      /* 5, main.lua:1073 */
+	int sm_terminate;  /* -sm_terminate <stage>: MC_SM_* below, 0 = run everything (main.lua:25,988-1075) */
+	int sm_skip;       /* -sm_skip <stage>: MC_SKIP_* below, 0 = skip nothing (main.lua:26,992-1077) */
 } mc_params;
+
+/* -sm_terminate stages, in pipeline order (the stereo method stops being "active" after the named stage) */
+enum { MC_SM_NONE = 0, MC_SM_CNN = 1, MC_SM_CBCA1 = 2, MC_SM_SGM = 3, MC_SM_CBCA2 = 4, MC_SM_OCCLUSION = 5,
+       MC_SM_MISMATCH = 6, MC_SM_SUBPIXEL = 7, MC_SM_MEDIAN = 8, MC_SM_BILATERAL = 9 };
+/* -sm_skip stages ('cbca' skips both aggregation blocks, 'occlusion' both interpolations, as in main.lua) */
+enum { MC_SKIP_NONE = 0, MC_SKIP_CBCA = 1, MC_SKIP_SGM = 2, MC_SKIP_OCCLUSION = 3, MC_SKIP_SUBPIXEL = 4,
+       MC_SKIP_MEDIAN = 5, MC_SKIP_BILATERAL = 6 };
 
 /* Workspace bytes mc_predict needs for the given problem. */
 size_t mc_predict_workspace_bytes(const mc_params *p, int C, int D, int H, int W);

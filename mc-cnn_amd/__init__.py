@@ -12,7 +12,7 @@ from . import _lib  # noqa: F401
 from . import adcensus  # noqa: F401
 from . import batch  # noqa: F401
 from .binio import read_bin, write_bin  # noqa: F401
-from .params import PRESETS, make_params  # noqa: F401
+from .params import NET_SHAPES, PRESETS, TABLES, make_params  # noqa: F401
 from .predict import stereo_predict, stereo_predict_fused, workspace_bytes  # noqa: F401
 
 __all__ = ["adcensus", "batch", "stereo_predict", "stereo_predict_fused", "workspace_bytes", "read_bin", "write_bin",

@@ -66,7 +66,7 @@ def _load():
         fn.argtypes = argtypes
         if name not in ("mc_sgm2_tmp_bytes", "mc_cbca_scratch_bytes"):
             fn.restype = C.c_int
-    if lib.mc_version() != 1:
+    if lib.mc_version() != 2:
         raise ImportError("mc-cnn_amd: ABI version mismatch")
     return lib
 

@@ -156,6 +156,8 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	MC_REQUIRE(p->cbca_i1 >= 0 && p->cbca_i2 >= 0 && p->sgm_i >= 0, "mc_predict: negative iteration count");
 	MC_REQUIRE(p->median_k % 2 == 1 && p->median_k <= 11, "mc_predict: median_k must be odd and <= 11");
 	MC_REQUIRE(p->blur_sigma > 0, "mc_predict: blur_sigma must be > 0");
+	MC_REQUIRE(p->sm_terminate >= 0 && p->sm_terminate <= MC_SM_BILATERAL && p->sm_skip >= 0 && p->sm_skip <= MC_SKIP_BILATERAL,
+	           "mc_predict: bad sm_terminate / sm_skip");
 	const bool from_feat = featL != nullptr;
 	if (from_feat) MC_REQUIRE(p->border_n >= 0 && p->border_n < W, "mc_predict: border_n=%d out of range", p->border_n);
 	const Plan pl = make_plan(p, D, H, W);
@@ -185,10 +187,20 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 
 	// index 0 = left volume (direction -1), 1 = right volume (direction +1)  (main.lua:986)
 	const int direction[2] = {-1, 1};
-	const bool use_cbca = (p->cbca_i1 + p->cbca_i2) > 0;
+	// sm_active / -sm_terminate / -sm_skip (main.lua:956,988-1040): identical for both directions, so they reduce to
+	// effective iteration counts of the three volume stages
+	bool sm_active = true;
+	sm_active = sm_active && p->sm_terminate != MC_SM_CNN;
+	const int n_cbca1 = (sm_active && p->sm_skip != MC_SKIP_CBCA) ? p->cbca_i1 : 0;
+	sm_active = sm_active && p->sm_terminate != MC_SM_CBCA1;
+	const int n_sgm = (sm_active && p->sm_skip != MC_SKIP_SGM) ? p->sgm_i : 0;
+	sm_active = sm_active && p->sm_terminate != MC_SM_SGM;
+	const int n_cbca2 = (sm_active && p->sm_skip != MC_SKIP_CBCA) ? p->cbca_i2 : 0;
+	sm_active = sm_active && p->sm_terminate != MC_SM_CBCA2;
+	const bool use_cbca = (n_cbca1 + n_cbca2) > 0;
 	tm.mark(-1);
 
-	if (p->sgm_i > 0) RUN(sgm_prep(x0, x1, maps, H, W, p->tau_so, st));
+	if (n_sgm > 0) RUN(sgm_prep(x0, x1, maps, H, W, p->tau_so, st));
 	if (use_cbca) {  // main.lua:993-996: x0c from the LEFT image, x1c from the RIGHT, for both directions
 		RUN(cross(x0, x0c, H, W, p->L1, p->tau1, st));
 		RUN(cross(x1, x1c, H, W, p->L1, p->tau1, st));
@@ -206,7 +218,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	bool hwd;  // layout of cur[]
 	// the MFMA StereoJoin addresses one image row of a volume and one feature map with 32-bit byte offsets
 	const bool join_fits = (int64_t)W * ((D + 3) / 4 * 4) * 4 < ((int64_t)1 << 31) && ((int64_t)C * HW + W) * 4 < ((int64_t)1 << 31);
-	if (from_feat && p->cbca_i1 == 0 && p->sgm_i > 0 && join_fits) {
+	if (from_feat && n_cbca1 == 0 && n_sgm > 0 && join_fits) {
 		// fast path: StereoJoin straight into (H,W,ds) with NaN fill and fix_border folded in
 		RUN(stereo_join_hwd(featL, featR, bufA[0], bufA[1], C, D, ds, H, W, p->border_n, st));
 		cur[0] = bufA[0]; cur[1] = bufA[1];
@@ -225,7 +237,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		}
 		hwd = false;
 		tm.mark(ST_JOIN);
-		for (int i = 0; i < p->cbca_i1; ++i) {  // main.lua:998-1001 (ping-pong instead of vol:copy(tmp))
+		for (int i = 0; i < n_cbca1; ++i) {  // main.lua:998-1001 (ping-pong instead of vol:copy(tmp))
 			for (int v = 0; v < 2; ++v) {
 				float *dst = other(v);
 				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29)) RUN(cbca_tiled(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
@@ -239,7 +251,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	// ---- (B) SGM, main.lua:1007-1030 ----
 	float *dispv[2] = {img[0], img[1]};  // [0] = left disparity (disp[2] in Lua), [1] = right
 	bool have_disp = false;
-	if (p->sgm_i > 0) {
+	if (n_sgm > 0) {
 		if (!hwd) {  // vol:transpose(2,3):transpose(3,4):clone(), main.lua:1008
 			for (int v = 0; v < 2; ++v) {
 				float *dst = other(v);
@@ -249,19 +261,19 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 			hwd = true;
 			tm.mark(ST_LAYOUT);
 		}
-		for (int it = 0; it < p->sgm_i; ++it) {
+		for (int it = 0; it < n_sgm; ++it) {
 			// out:zero(); sgm2(...); vol:copy(out):div(4)  (main.lua:1013-1018): the zero is folded
 			// into the first sweep (0 + L_0) and the /4 into the last
 			const float *Cv[2] = {cur[0], cur[1]};
 			float *outv[2] = {other(0), other(1)};
-			const bool am = (it == p->sgm_i - 1) && p->cbca_i2 == 0;
+			const bool am = (it == n_sgm - 1) && n_cbca2 == 0;
 			RUN(sgm_sweeps(Cv, outv, bufC, am ? dispv : nullptr, direction, 2, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
 			               p->sgm_q1, p->sgm_q2, true, st));
 			have_disp = am;
 			cur[0] = outv[0]; cur[1] = outv[1];
 		}
 		tm.mark(ST_SGM);
-		if (p->cbca_i2 > 0) {  // back to (D,H,W): vol:copy(out:transpose(3,4):transpose(2,3)), main.lua:1019-1020
+		if (n_cbca2 > 0) {  // back to (D,H,W): vol:copy(out:transpose(3,4):transpose(2,3)), main.lua:1019-1020
 			for (int v = 0; v < 2; ++v) {
 				float *dst = other(v);
 				RUN(transpose(cur[v], dst, HW, D, ds, HW, 1.0f, st));
@@ -272,7 +284,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		}
 	}
 	if (!hwd) {  // CBCA-2, main.lua:1033-1039
-		for (int i = 0; i < p->cbca_i2; ++i) {
+		for (int i = 0; i < n_cbca2; ++i) {
 			for (int v = 0; v < 2; ++v) {
 				float *dst = other(v);
 				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29)) RUN(cbca_tiled(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
@@ -302,22 +314,47 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	tm.mark(ST_ARGMIN);
 
 	// ---- (C) post-processing on the LEFT disparity, main.lua:1054-1081 ----
+	// every stage reads `d` and writes the next free image; -sm_skip / -sm_terminate drop stages (main.lua:1057-1079)
 	float *d = dispv[0];
-	float *t = img[2];
-	float *t2 = img[3];
 	float *outl = img[4];
+	int nfree = 0;
+	float *freeimg[3] = {img[2], img[3], img[5]};
+	auto next = [&]() -> float * {
+		float *r = freeimg[nfree % 3];
+		if (r == d) r = freeimg[++nfree % 3];
+		++nfree;
+		return r;
+	};
 	if (p->lr_check) {
 		RUN(outlier_detection(d, dispv[1], outl, H, W, D, st));
-		RUN(interpolate_occlusion(d, outl, t, H, W, st));
-		RUN(interpolate_mismatch(t, outl, t2, H, W, st));
-		d = t2;
-		t2 = img[5];
+		if (sm_active && p->sm_skip != MC_SKIP_OCCLUSION) {
+			float *o = next();
+			RUN(interpolate_occlusion(d, outl, o, H, W, st));
+			d = o;
+		}
+		sm_active = sm_active && p->sm_terminate != MC_SM_OCCLUSION;
+		if (sm_active && p->sm_skip != MC_SKIP_OCCLUSION) {
+			float *o = next();
+			RUN(interpolate_mismatch(d, outl, o, H, W, st));
+			d = o;
+		}
+		sm_active = sm_active && p->sm_terminate != MC_SM_MISMATCH;
 	}
-	// subpixel on the LEFT volume (vol of the last loop iteration, main.lua:1068)
-	if (hwd) RUN(subpixel(d, cur[0], t, D, H, W, 1, ds, st));
-	else RUN(subpixel(d, cur[0], t, D, H, W, HW, 1, st));
-	RUN(median2d(t, t2, H, W, p->median_k, st));
-	{
+	if (sm_active && p->sm_skip != MC_SKIP_SUBPIXEL) {
+		// subpixel on the LEFT volume (vol of the last loop iteration, main.lua:1068)
+		float *o = next();
+		if (hwd) RUN(subpixel(d, cur[0], o, D, H, W, 1, ds, st));
+		else RUN(subpixel(d, cur[0], o, D, H, W, HW, 1, st));
+		d = o;
+	}
+	sm_active = sm_active && p->sm_terminate != MC_SM_SUBPIXEL;
+	if (sm_active && p->sm_skip != MC_SKIP_MEDIAN) {
+		float *o = next();
+		RUN(median2d(d, o, H, W, p->median_k, st));
+		d = o;
+	}
+	sm_active = sm_active && p->sm_terminate != MC_SM_MEDIAN;
+	if (sm_active && p->sm_skip != MC_SKIP_BILATERAL) {
 		const std::vector<float> &k = gaussian_cached(p->blur_sigma);
 		const int ks = 2 * (int)ceil(p->blur_sigma * 3) + 1;
 		const hipError_t e = hipMemcpyAsync(gk, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice, st);
@@ -325,7 +362,9 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 			set_error("mc_predict: kernel upload: %s", hipGetErrorString(e));
 			return (int)e;
 		}
-		RUN(mean2d(t2, gk, disp_out, H, W, ks, p->blur_t, st));
+		RUN(mean2d(d, gk, disp_out, H, W, ks, p->blur_t, st));
+	} else {
+		RUN(scale(d, disp_out, HW, 1.0f, st));  // the last stage that ran is the result
 	}
 	tm.mark(ST_POST);
 #undef RUN

@@ -1,0 +1,151 @@
+"""`main.lua -a predict` / `-a time` on MI355X: the host side of the reference's predict path in Python.
+
+    python -m mc_cnn_amd.main kitti fast -a predict -net_fname NET -left L.png -right R.png -disp_max 70
+
+mirrors `./main.lua kitti fast -a predict ...` (main.lua:10-32 flags, 1084-1105 action): loads the two images, converts
+RGB to luma, normalises each to zero mean / unit (unbiased) std on the host, uploads (2,1,H,W), runs the feature net
+(arch fast: l1 x [3x3 conv, pad 1, ReLU] with no ReLU after the last conv, then Normalize2 -- main.lua:727-746; the
+convolutions go through PyTorch-ROCm / MIOpen, everything after them through libmcadcensus.so), then the post-CNN
+pipeline in one `mc_predict` call, and writes `left.bin`, `right.bin` (1,D,H,W) and `disp.bin` (1,1,H,W), raw float32,
+with the reference's messages.  `-a time` is main.lua:1140-1167 (min of N runs on an uninitialised batch).
+
+-net_fname: the reference loads a Torch7 `.t7` file (main.lua:892-902), which this image cannot read (no Torch7); here
+it is an `.npz` with arrays w1,b1,...,w<l1>,b<l1> (w_i: (fm, in, 3, 3)), or `random:<seed>` for a seeded random net
+(there is no network access for trained weights).  Hyper-parameter flags (-L1 -tau1 -cbca_i1 -cbca_i2 -pi1 -pi2 -sgm_i
+-sgm_q1 -sgm_q2 -alpha1 -tau_so -blur_sigma -blur_t) default to main.lua's per-(dataset, arch) tables.
+"""
+import argparse
+import sys
+import time
+
+import numpy as np
+
+from .binio import write_bin
+from .params import NET_SHAPES, TABLES
+
+
+def rgb2y(img):
+    """image.rgb2y: Y = 0.299 R + 0.587 G + 0.114 B on a (3,H,W) float tensor."""
+    return (0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2])[None]
+
+
+def load_image(path):
+    """image.load(path, nil, 'byte'):float() -> (C,H,W) float32 in 0..255."""
+    from PIL import Image
+    a = np.asarray(Image.open(path))
+    if a.ndim == 2:
+        a = a[None]
+    else:
+        a = np.transpose(a[:, :, :3], (2, 0, 1))
+    return a.astype(np.float32)
+
+
+def normalize(x):
+    """x:add(-x:mean()):div(x:std()) -- torch's unbiased std, accumulations in double (main.lua:1095-1096)."""
+    xd = x.astype(np.float64)
+    return ((x - np.float32(xd.mean())) / np.float32(xd.std(ddof=1))).astype(np.float32)
+
+
+def parse(argv):
+    if len(argv) < 2 or argv[0] not in ("kitti", "kitti2015", "mb") or argv[1] not in ("fast", "slow", "ad", "census"):
+        raise SystemExit("usage: main.py {kitti|kitti2015|mb} {fast|slow|ad|census} -a {predict|time} [flags]  (main.lua:10-13)")
+    dataset, arch = argv[0], argv[1]
+    t = TABLES[(dataset, arch)]
+    ap = argparse.ArgumentParser(prog="main.py %s %s" % (dataset, arch), prefix_chars="-")
+    ap.add_argument("-a", default="predict", choices=["predict", "time"])
+    ap.add_argument("-net_fname", default="random:42")
+    ap.add_argument("-left", default="")
+    ap.add_argument("-right", default="")
+    ap.add_argument("-disp_max", type=int, default=228 if dataset != "mb" else 200)
+    ap.add_argument("-gpu", type=int, default=1, help="1-based, as cutorch.setDevice (main.lua:16,342)")
+    ap.add_argument("-tiny", action="store_true")
+    for k in ("L1", "cbca_i1", "cbca_i2", "sgm_i"):
+        ap.add_argument("-" + k, type=int, default=t[k])
+    for k in ("tau1", "pi1", "pi2", "sgm_q1", "sgm_q2", "alpha1", "tau_so", "blur_sigma", "blur_t"):
+        ap.add_argument("-" + k, type=float, default=t[k])
+    opt = ap.parse_args(argv[2:])
+    prm = dict(t)
+    for k in ("L1", "cbca_i1", "cbca_i2", "sgm_i", "tau1", "pi1", "pi2", "sgm_q1", "sgm_q2", "alpha1", "tau_so", "blur_sigma",
+              "blur_t"):
+        prm[k] = getattr(opt, k)
+    return dataset, arch, opt, prm
+
+
+def load_net(net_fname, dataset, arch, n_input_plane=1):
+    """[(w, b)] of the feature net: from an .npz, or seeded random (`random:<seed>`)."""
+    l1, fm = NET_SHAPES[(dataset, arch)]
+    if net_fname.startswith("random:"):
+        rng = np.random.default_rng(int(net_fname.split(":")[1]))
+        layers = []
+        for i in range(l1):
+            cin = n_input_plane if i == 0 else fm
+            bound = 1.0 / np.sqrt(cin * 9)  # nn.SpatialConvolution:reset() range
+            layers.append((rng.uniform(-bound, bound, (fm, cin, 3, 3)).astype(np.float32),
+                           rng.uniform(-bound, bound, (fm,)).astype(np.float32)))
+        return layers
+    z = np.load(net_fname)
+    return [(z["w%d" % (i + 1)].astype(np.float32), z["b%d" % (i + 1)].astype(np.float32)) for i in range(l1)]
+
+
+def features_fast(x_batch, layers):
+    """forward_free(net_te, x_batch) for arch fast (main.lua:945): convs (pad 1) + ReLU between, then Normalize2."""
+    import torch
+    import torch.nn.functional as F
+    from . import adcensus
+    h = x_batch
+    for i, (w, b) in enumerate(layers):
+        h = F.conv2d(h, torch.from_numpy(w).to(h.device), torch.from_numpy(b).to(h.device), padding=1)
+        if i < len(layers) - 1:
+            h = F.relu(h)
+    h = h.contiguous()
+    norm = torch.empty((h.shape[0], 1) + tuple(h.shape[2:]), dtype=torch.float32, device=h.device)
+    out = torch.empty_like(h)
+    adcensus.Normalize_forward(h, norm, out)   # Normalize2.lua:8-13 -> adcensus.cu:1310-1333
+    return out
+
+
+def main(argv=None):
+    dataset, arch, opt, prm = parse(list(sys.argv[1:] if argv is None else argv))
+    import torch
+    from .predict import Workspace, stereo_predict_fused
+    if arch != "fast":
+        raise SystemExit("main.py: -a %s is wired for arch fast (the accurate net's FC stack is SURVEY 8(f-1)); use the "
+                         "library entry points with raw volumes for arch %s" % (opt.a, arch))
+    dev = torch.device("cuda", opt.gpu - 1)
+    torch.cuda.set_device(dev)
+    layers = load_net(opt.net_fname, dataset, arch)
+    prm["border_n"] = len(layers)  # (1 + l1*(3-1) - 1) / 2, main.lua:382-391,923
+    if opt.a == "time":  # main.lua:1140-1167
+        H, W, D = (240, 320, 32) if opt.tiny else ((350, 1242, 228) if dataset != "mb" else (1000, 1500, 200))
+        x_batch = torch.empty((2, 1, H, W), dtype=torch.float32, device=dev).normal_()
+        ws = Workspace(prm, D, H, W, dev)
+        best = float("inf")
+        for _ in range(30):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            feat = features_fast(x_batch, layers)
+            stereo_predict_fused(x_batch, prm, D, feat=feat, workspace=ws)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        print(best)
+        return 0
+    x0, x1 = load_image(opt.left), load_image(opt.right)
+    if x0.shape[0] == 3:
+        assert x1.shape[0] == 3
+        x0, x1 = rgb2y(x0), rgb2y(x1)
+    D = opt.disp_max
+    x_batch = torch.from_numpy(np.stack([normalize(x0), normalize(x1)])).to(dev)  # (2,1,H,W)
+    feat = features_fast(x_batch, layers)
+    res = stereo_predict_fused(x_batch, prm, D, feat=feat, want_volumes=True)
+    torch.cuda.synchronize()
+    H, W = x_batch.shape[2:]
+    for name, key in (("right", "volR"), ("left", "volL")):  # main.lua:954-955 writes right.bin first
+        print("Writing %s.bin, %d x %d x %d x %d" % (name, 1, D, H, W))
+        write_bin("%s.bin" % name, res[key].cpu().numpy())
+    print("Writing disp.bin, %d x %d x %d x %d" % (1, 1, H, W))
+    write_bin("disp.bin", res["disp"].cpu().numpy())
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -29,6 +29,7 @@ class OracleParams(C.Structure):
         ("sgm_q1", C.c_float), ("sgm_q2", C.c_float), ("alpha1", C.c_float), ("tau_so", C.c_float),
         ("blur_sigma", C.c_double), ("blur_t", C.c_float),
         ("lr_check", C.c_int), ("border_n", C.c_int), ("median_k", C.c_int),
+        ("sm_terminate", C.c_int), ("sm_skip", C.c_int),
     ]
 
 
@@ -219,8 +220,14 @@ def normalize_forward(x):
 
 def make_params(d):
     p = OracleParams()
+    term = {"": 0, "cnn": 1, "cbca1": 2, "sgm": 3, "cbca2": 4, "occlusion": 5, "mismatch": 6,
+            "subpixel_enchancement": 7, "median": 8, "bilateral": 9}
+    skip = {"": 0, "cbca": 1, "sgm": 2, "occlusion": 3, "subpixel_enchancement": 4, "median": 5, "bilateral": 6}
     for k, _ in OracleParams._fields_:
-        setattr(p, k, d[k])
+        v = d.get(k, 0) if k in ("sm_terminate", "sm_skip") else d[k]
+        if isinstance(v, str):
+            v = (term if k == "sm_terminate" else skip)[v]
+        setattr(p, k, v)
     return p
 
 

@@ -611,6 +611,8 @@ typedef struct {
 	int lr_check;   /* 1 for kitti / kitti2015 (main.lua:1054) */
 	int border_n;   /* fix_border width n = (ws-1)/2, features input only */
 	int median_k;   /* 5 (main.lua:1073) */
+	int sm_terminate; /* -sm_terminate: 0 none, 1 cnn, 2 cbca1, 3 sgm, 4 cbca2, 5 occlusion, 6 mismatch, 7 subpixel, 8 median, 9 bilateral */
+	int sm_skip;      /* -sm_skip: 0 none, 1 cbca, 2 sgm, 3 occlusion, 4 subpixel, 5 median, 6 bilateral */
 } oracle_params;
 
 /*
@@ -656,19 +658,29 @@ API int oracle_stereo_predict(const oracle_params *p, const float *x0, const flo
 	oracle_cross(x0, x0c, H, W, p->L1, p->tau1);
 	oracle_cross(x1, x1c, H, W, p->L1, p->tau1);
 
+	/* sm_active / -sm_terminate / -sm_skip, main.lua:956,988-1040: the same for both directions */
+	int sm_active = 1;
+	sm_active = sm_active && p->sm_terminate != 1;            /* 'cnn' */
+	const int do_cbca1 = sm_active && p->sm_skip != 1;        /* skip 'cbca' */
+	sm_active = sm_active && p->sm_terminate != 2;            /* 'cbca1' */
+	const int do_sgm = sm_active && p->sm_skip != 2;
+	sm_active = sm_active && p->sm_terminate != 3;            /* 'sgm' */
+	const int do_cbca2 = sm_active && p->sm_skip != 1;
+	sm_active = sm_active && p->sm_terminate != 4;            /* 'cbca2' */
+
 	const int directions[2] = {1, -1}; /* main.lua:954-955 */
 	for (int k = 0; k < 2; k++) {
 		const int direction = directions[k];
 		float *vol = direction == -1 ? vols[0] : vols[1];
 
-		for (int i = 0; i < p->cbca_i1; i++) { /* main.lua:998-1001 */
+		for (int i = 0; do_cbca1 && i < p->cbca_i1; i++) { /* main.lua:998-1001 */
 			oracle_cbca(x0c, x1c, vol, buf, D, H, W, direction);
 			memcpy(vol, buf, sizeof(float) * V);
 		}
 
 		/* main.lua:1008-1020 */
 		oracle_dhw_to_hwd(vol, buf, D, H, W); /* buf = vol (H,W,D) */
-		for (int i = 0; i < p->sgm_i; i++) {
+		for (int i = 0; do_sgm && i < p->sgm_i; i++) {
 			memset(buf2, 0, sizeof(float) * V);
 			rc = oracle_sgm2(x0, x1, buf, buf2, H, W, D, p->pi1, p->pi2, p->tau_so, p->alpha1,
 			                 p->sgm_q1, p->sgm_q2, direction);
@@ -676,13 +688,13 @@ API int oracle_stereo_predict(const oracle_params *p, const float *x0, const flo
 #pragma omp parallel for
 			for (int64_t j = 0; j < V; j++) buf[j] = buf2[j] / 4;
 		}
-		if (p->sgm_i > 0) {
+		if (do_sgm && p->sgm_i > 0) {
 			oracle_hwd_to_dhw(buf2, vol, D, H, W);
 #pragma omp parallel for
 			for (int64_t j = 0; j < V; j++) vol[j] = vol[j] / 4;
 		}
 
-		for (int i = 0; i < p->cbca_i2; i++) { /* main.lua:1033-1039 */
+		for (int i = 0; do_cbca2 && i < p->cbca_i2; i++) { /* main.lua:1033-1039 */
 			oracle_cbca(x0c, x1c, vol, buf, D, H, W, direction);
 			memcpy(vol, buf, sizeof(float) * V);
 		}
@@ -700,19 +712,31 @@ API int oracle_stereo_predict(const oracle_params *p, const float *x0, const flo
 	memset(outl, 0, sizeof(float) * HW);
 	if (p->lr_check) { /* main.lua:1054-1066 */
 		oracle_outlier_detection(cur, disp[0], outl, H, W, D);
-		oracle_interpolate_occlusion(cur, outl, alt, H, W);
-		{ float *s = cur; cur = alt; alt = s; }
-		oracle_interpolate_mismatch(cur, outl, alt, H, W);
-		{ float *s = cur; cur = alt; alt = s; }
+		if (sm_active && p->sm_skip != 3) {
+			oracle_interpolate_occlusion(cur, outl, alt, H, W);
+			{ float *s = cur; cur = alt; alt = s; }
+		}
+		sm_active = sm_active && p->sm_terminate != 5;
+		if (sm_active && p->sm_skip != 3) {
+			oracle_interpolate_mismatch(cur, outl, alt, H, W);
+			{ float *s = cur; cur = alt; alt = s; }
+		}
+		sm_active = sm_active && p->sm_terminate != 6;
 	}
 	if (outlier_out) memcpy(outlier_out, outl, sizeof(float) * HW);
 
 	/* main.lua:1067-1069: vol is the LEFT volume (last loop iteration) */
-	oracle_subpixel_enchancement(cur, vols[0], alt, D, H, W);
-	{ float *s = cur; cur = alt; alt = s; }
-	oracle_median2d(cur, alt, H, W, p->median_k); /* main.lua:1072-1074 */
-	{ float *s = cur; cur = alt; alt = s; }
-	{
+	if (sm_active && p->sm_skip != 4) {
+		oracle_subpixel_enchancement(cur, vols[0], alt, D, H, W);
+		{ float *s = cur; cur = alt; alt = s; }
+	}
+	sm_active = sm_active && p->sm_terminate != 7;
+	if (sm_active && p->sm_skip != 5) {
+		oracle_median2d(cur, alt, H, W, p->median_k); /* main.lua:1072-1074 */
+		{ float *s = cur; cur = alt; alt = s; }
+	}
+	sm_active = sm_active && p->sm_terminate != 8;
+	if (sm_active && p->sm_skip != 6) {
 		int ks = oracle_gaussian(p->blur_sigma, NULL, 0); /* main.lua:1077-1079 */
 		float *k = (float *)malloc(sizeof(float) * ks * ks);
 		oracle_gaussian(p->blur_sigma, k, ks * ks);

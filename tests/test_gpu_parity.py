@@ -291,6 +291,70 @@ def test_stereo_predict(mc, oracle, name, over, H, W, D, C, driver):
     assert_same(host(got["disp"]), want["disp"], "disp.bin")
 
 
+SWITCHES = [dict(sm_terminate=t) for t in ("cnn", "cbca1", "sgm", "cbca2", "occlusion", "mismatch", "subpixel_enchancement",
+                                            "median", "bilateral")] + \
+           [dict(sm_skip=k) for k in ("cbca", "sgm", "occlusion", "subpixel_enchancement", "median", "bilateral")]
+
+
+@pytest.mark.parametrize("sw", SWITCHES, ids=lambda d: "%s=%s" % tuple(d.items())[0])
+@pytest.mark.parametrize("name,C", [("kitti_fast", 16), ("kitti2015_slow", 0), ("mb_slow", 0)])
+def test_sm_terminate_and_skip(mc, oracle, sw, name, C):
+    """-sm_terminate <stage> / -sm_skip <stage> (main.lua:25-26, 956, 988-1079) in the fused entry point."""
+    H, W, D = 20, 72, 20
+    prm = dict(mc.PRESETS[name])
+    if name == "mb_slow":
+        prm["cbca_i2"] = 2
+    prm.update(sw)
+    x0, x1 = smooth_pair(H, W, 10, seed=31)
+    xb = dev(np.stack([x0, x1]))[:, None]
+    if C:
+        f = features(C, H, W, seed=5)
+        want = oracle.stereo_predict(prm, x0, x1, D, featL=f[0], featR=f[1])
+        kw = dict(feat=dev(f))
+    else:
+        vl, vr = raw_volumes(D, H, W, seed=7)
+        want = oracle.stereo_predict(prm, x0, x1, D, rawL=vl, rawR=vr)
+        kw = dict(raw=(dev(vl), dev(vr)))
+    got = mc.stereo_predict_fused(xb, prm, D, want_volumes=True, want_disp0=True, **kw)
+    torch.cuda.synchronize()
+    for k in ("volL", "volR", "dispL0", "dispR0", "disp"):
+        assert_same(host(got[k]), want[k], k)
+
+
+def test_main_predict_writes_the_reference_files(mc, oracle, tmp_path, monkeypatch):
+    """`main.py kitti fast -a predict -left L.png -right R.png -disp_max D` (main.lua:1084-1105): left.bin / right.bin /
+    disp.bin with the reference's layout; contents bit-exact vs the oracle fed with the same features."""
+    from PIL import Image
+    from mc_cnn_amd import main as mcmain
+    H, W, D = 40, 96, 24
+    rng = np.random.default_rng(3)
+    from scipy.ndimage import gaussian_filter
+    base = gaussian_filter(rng.random((H, W + 8)), 2.0)
+    base = ((base - base.min()) / np.ptp(base) * 255).astype(np.uint8)
+    Image.fromarray(base[:, 8:]).save(tmp_path / "L.png")
+    Image.fromarray(np.stack([base[:, :W]] * 3, axis=-1)).save(tmp_path / "R.png")  # RGB on purpose: rgb2y path
+    Image.fromarray(np.stack([base[:, 8:]] * 3, axis=-1)).save(tmp_path / "L3.png")
+    monkeypatch.chdir(tmp_path)
+    assert mcmain.main(["kitti", "fast", "-a", "predict", "-net_fname", "random:7", "-left", "L3.png", "-right", "R.png",
+                        "-disp_max", str(D)]) == 0
+    left = mc.read_bin("left.bin", (1, D, H, W))
+    right = mc.read_bin("right.bin", (1, D, H, W))
+    disp = mc.read_bin("disp.bin", (1, 1, H, W))
+    assert (tmp_path / "left.bin").stat().st_size == 4 * D * H * W
+    # the same host path by hand, then the oracle on the resulting features
+    x0 = mcmain.normalize(mcmain.rgb2y(mcmain.load_image("L3.png")))
+    x1 = mcmain.normalize(mcmain.rgb2y(mcmain.load_image("R.png")))
+    xb = dev(np.stack([x0, x1]))
+    layers = mcmain.load_net("random:7", "kitti", "fast")
+    feat = host(mcmain.features_fast(xb, layers))
+    prm = dict(mc.TABLES[("kitti", "fast")])
+    prm["border_n"] = len(layers)
+    want = oracle.stereo_predict(prm, x0[0], x1[0], D, featL=feat[0], featR=feat[1])
+    assert_same(left, want["volL"], "left.bin")
+    assert_same(right, want["volR"], "right.bin")
+    assert_same(disp, want["disp"], "disp.bin")
+
+
 def test_errors_are_loud(mc):
     """Bad arguments raise (reference: Lua error), they never fall back."""
     t = torch.zeros((1, 4, 8, 8), device="cuda")
