@@ -65,6 +65,12 @@ int mc_ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int
 int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W,
               int direction, void *stream);
 
+/* The same operator from per-pixel census signatures (81 comparison bits per pixel and channel, computed once
+ * instead of once per disparity) held in `scratch` (mc_census_scratch_bytes); bit-identical to mc_census. */
+size_t mc_census_scratch_bytes(int Cimg, int H, int W);
+int mc_census_ws(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W,
+                 int direction, void *scratch, size_t scratch_bytes, void *stream);
+
 /* fix_border(net, vol, direction), main.lua:922-927: n = (window-1)/2 columns. */
 int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream);
 

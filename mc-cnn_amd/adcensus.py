@@ -31,6 +31,14 @@ def _p(t):
     return t.data_ptr()
 
 
+def _scratch_for(device, need):
+    key = (device.index, need)
+    scratch = _scratch.get(key)
+    if scratch is None:
+        scratch = _scratch[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return scratch
+
+
 def ad(x0, x1, out, direction):
     """adcensus.ad(x0, x1, out, direction) -- adcensus.cu:95-114."""
     _chk(x0, x1, out)
@@ -39,7 +47,19 @@ def ad(x0, x1, out, direction):
 
 
 def census(x0, x1, out, direction):
-    """adcensus.census(x0, x1, out, direction) -- adcensus.cu:155-175 (channels = x0:size(2))."""
+    """adcensus.census(x0, x1, out, direction) -- adcensus.cu:155-175 (channels = x0:size(2)).  Runs the signature
+    form (mc_census_ws) with a cached per-shape scratch."""
+    _chk(x0, x1, out)
+    D, H, W = out.shape[-3:]
+    cimg = x0.shape[-3] if x0.dim() >= 3 else 1
+    need = lib.mc_census_scratch_bytes(cimg, H, W)
+    scratch = _scratch_for(out.device, need)
+    check(lib.mc_census_ws(_p(x0), _p(x1), _p(out), cimg, D, H, W, int(direction), scratch.data_ptr(), need, _stream()),
+          "census")
+
+
+def census_reference_shaped(x0, x1, out, direction):
+    """The same operator through mc_census (one thread per voxel, 81 taps per channel per disparity)."""
     _chk(x0, x1, out)
     D, H, W = out.shape[-3:]
     cimg = x0.shape[-3] if x0.dim() >= 3 else 1
@@ -60,14 +80,6 @@ def cross(x0, out, L1, tau1):
     _chk(x0, out)
     H, W = out.shape[-2:]
     check(lib.mc_cross(_p(x0), _p(out), H, W, int(L1), float(tau1), _stream()), "cross")
-
-
-def _scratch_for(device, need):
-    key = (device.index, need)
-    scratch = _scratch.get(key)
-    if scratch is None:
-        scratch = _scratch[key] = torch.empty(need, dtype=torch.uint8, device=device)
-    return scratch
 
 
 def cbca(x0c, x1c, vol_in, vol_out, direction):

@@ -26,8 +26,11 @@ int normalize_forward(const float *in, float *norm, float *out, int N, int C, in
 int stereo_join_dhw(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int H, int W, hipStream_t st);
 int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int ds, int H, int W, int n,
                     hipStream_t st);
-int ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, hipStream_t st);
 int census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, hipStream_t st);
+int ad_tiled(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, hipStream_t st);
+size_t census_scratch_bytes(int Cimg, int H, int W);
+int census_sig(const float *x0, const float *x1, float *vol, void *scratch, int Cimg, int D, int H, int W, int direction,
+               hipStream_t st);
 int cross(const float *img, float *arms, int H, int W, int L1, float tau1, hipStream_t st);
 int cbca(const float *x0c, const float *x1c, const float *vin, float *vout, int D, int H, int W, int direction, hipStream_t st);
 size_t cbca_scratch_bytes(int H, int W);
@@ -401,7 +404,8 @@ int mc_ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int
 	MC_REQUIRE(x0 && x1 && vol, "mc_ad: null pointer");
 	MC_REQUIRE(dims_ok(D, H, W), "mc_ad: bad dims");
 	MC_REQUIRE(direction == -1 || direction == 1, "mc_ad: direction must be -1 or 1");
-	return ad(x0, x1, vol, D, H, W, direction, as_stream(stream));
+	MC_REQUIRE(D <= 65535, "mc_ad: D too large");
+	return ad_tiled(x0, x1, vol, D, H, W, direction, as_stream(stream));
 }
 
 int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, void *stream)
@@ -410,6 +414,24 @@ int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int
 	MC_REQUIRE(dims_ok(D, H, W) && Cimg >= 1, "mc_census: bad dims");
 	MC_REQUIRE(direction == -1 || direction == 1, "mc_census: direction must be -1 or 1");
 	return census(x0, x1, vol, Cimg, D, H, W, direction, as_stream(stream));
+}
+
+size_t mc_census_scratch_bytes(int Cimg, int H, int W)
+{
+	if (Cimg < 1 || H < 1 || W < 1) return 0;
+	return census_scratch_bytes(Cimg, H, W);
+}
+
+int mc_census_ws(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, void *scratch,
+                 size_t scratch_bytes, void *stream)
+{
+	MC_REQUIRE(x0 && x1 && vol && scratch, "mc_census_ws: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W) && Cimg >= 1 && D <= 65535, "mc_census_ws: bad dims");
+	MC_REQUIRE(direction == -1 || direction == 1, "mc_census_ws: direction must be -1 or 1");
+	MC_REQUIRE(scratch_bytes >= census_scratch_bytes(Cimg, H, W), "mc_census_ws: scratch holds %zu bytes, needs %zu", scratch_bytes,
+	           census_scratch_bytes(Cimg, H, W));
+	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_census_ws: scratch must be 4-byte aligned");
+	return census_sig(x0, x1, vol, scratch, Cimg, D, H, W, direction, as_stream(stream));
 }
 
 int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream)

@@ -214,45 +214,6 @@ int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, 
 	return check_launch("fix_border_hwd");
 }
 
-// ---- ad, adcensus.cu:62-93 ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ad_kernel(const float *__restrict__ x0, const float *__restrict__ x1, float *__restrict__ out,
-                                                 int64_t size, int H, int W, int direction)
-{
-	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (id >= size) return;
-	int64_t t = id;
-	const int x = (int)(t % W);
-	t /= W;
-	const int y = (int)(t % H);
-	t /= H;
-	const int d = (int)t * direction;
-	float dist;
-	if (0 <= x + d && x + d < W) {
-		int cnt = 0;
-		dist = 0;
-		for (int yy = y - 4; yy <= y + 4; yy++) {
-			for (int xx = x - 4; xx <= x + 4; xx++) {
-				if (0 <= xx && xx < W && 0 <= xx + d && xx + d < W && 0 <= yy && yy < H) {
-					const int ind = yy * W + xx;
-					dist += fabsf(x0[ind] - x1[ind + d]);
-					cnt++;
-				}
-			}
-		}
-		dist /= cnt;
-	} else {
-		dist = __builtin_nanf("");
-	}
-	out[id] = dist;
-}
-
-int ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, hipStream_t st)
-{
-	const int64_t size = (int64_t)D * H * W;
-	hipLaunchKernelGGL(ad_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, x0, x1, vol, size, H, W, direction);
-	return check_launch("ad");
-}
-
 // ---- census, adcensus.cu:117-153 -----------------------------------------------------------------------
 __global__ void __launch_bounds__(256) census_kernel(const float *__restrict__ x0, const float *__restrict__ x1,
                                                      float *__restrict__ out, int64_t size, int Cimg, int H, int W, int direction)
@@ -293,6 +254,147 @@ int census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H,
 	const int64_t size = (int64_t)D * H * W;
 	hipLaunchKernelGGL(census_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, x0, x1, vol, size, Cimg, H, W, direction);
 	return check_launch("census");
+}
+
+
+// ---- census, signature form ---------------------------------------------------------------------
+// The 81 comparisons x[q] < x[p] of a pixel's 9x9 window do not depend on the disparity: census_sig_kernel packs them
+// once per pixel and channel into 81 bits (3 words; taps outside the image are 0) together with the window's
+// in-image mask.  The cost of voxel (d,y,x) is then, per channel,
+//     (81 - popcount(V)) + popcount((S0[y,x] ^ S1[y,x+d]) & V),   V = mask[y,x] & mask[y,x+d]
+// -- the reference's count of out-of-bounds taps plus differing in-bounds taps (adcensus.cu:128-144): small integers,
+// so the float result (sum, then / channels) is bit-identical.
+__global__ void __launch_bounds__(256) census_sig_kernel(const float *__restrict__ img, uint32_t *__restrict__ sig,
+                                                         uint32_t *__restrict__ mask, int Cimg, int H, int W)
+{
+	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t HW = (int64_t)H * W;
+	if (id >= (int64_t)Cimg * HW) return;
+	const int c = (int)(id / HW);
+	const int64_t pix = id - c * HW;
+	const int x = (int)(pix % W), y = (int)(pix / W);
+	const float *__restrict__ im = img + c * HW;
+	const float p = im[pix];
+	uint32_t s[3] = {0, 0, 0}, m[3] = {0, 0, 0};
+	int t = 0;
+	for (int yy = y - 4; yy <= y + 4; yy++) {
+		for (int xx = x - 4; xx <= x + 4; xx++, t++) {
+			if (0 <= xx && xx < W && 0 <= yy && yy < H) {
+				m[t >> 5] |= 1u << (t & 31);
+				if (im[(int64_t)yy * W + xx] < p) s[t >> 5] |= 1u << (t & 31);
+			}
+		}
+	}
+	uint32_t *so = sig + id * 3;
+	so[0] = s[0]; so[1] = s[1]; so[2] = s[2];
+	if (c == 0) {
+		uint32_t *mo = mask + pix * 3;
+		mo[0] = m[0]; mo[1] = m[1]; mo[2] = m[2];
+	}
+}
+
+__global__ void __launch_bounds__(256) census_cost_kernel(const uint32_t *__restrict__ sig0, const uint32_t *__restrict__ sig1,
+                                                          const uint32_t *__restrict__ mask, float *__restrict__ out, int Cimg, int D,
+                                                          int H, int W, int direction)
+{
+	const int x = blockIdx.x * 256 + threadIdx.x;
+	const int y = blockIdx.y;
+	const int d = blockIdx.z * direction;
+	if (x >= W) return;
+	const int64_t HW = (int64_t)H * W;
+	const int64_t pix = (int64_t)y * W + x;
+	float dist;
+	if (0 <= x + d && x + d < W) {
+		const uint32_t *m0 = mask + pix * 3, *m1 = mask + (pix + d) * 3;
+		const uint32_t v0 = m0[0] & m1[0], v1 = m0[1] & m1[1], v2 = m0[2] & m1[2];
+		const int oob = 81 - (__popc(v0) + __popc(v1) + __popc(v2));
+		dist = 0;
+		for (int c = 0; c < Cimg; c++) {
+			const uint32_t *a = sig0 + (c * HW + pix) * 3, *b = sig1 + (c * HW + pix + d) * 3;
+			const int diff = __popc((a[0] ^ b[0]) & v0) + __popc((a[1] ^ b[1]) & v1) + __popc((a[2] ^ b[2]) & v2);
+			// the reference counts in a float accumulator (dist++); every partial count is an integer <= 81*Cimg, exact
+			dist += (float)(oob + diff);
+		}
+		dist /= (float)Cimg;
+	} else {
+		dist = __builtin_nanf("");
+	}
+	out[(int64_t)blockIdx.z * HW + pix] = dist;
+}
+
+size_t census_scratch_bytes(int Cimg, int H, int W)
+{
+	return (((size_t)2 * Cimg + 1) * H * W * 3 * sizeof(uint32_t) + 255) & ~(size_t)255;
+}
+
+int census_sig(const float *x0, const float *x1, float *vol, void *scratch, int Cimg, int D, int H, int W, int direction,
+               hipStream_t st)
+{
+	const int64_t HW = (int64_t)H * W;
+	uint32_t *s0 = (uint32_t *)scratch, *s1 = s0 + (size_t)Cimg * HW * 3, *mk = s1 + (size_t)Cimg * HW * 3;
+	hipLaunchKernelGGL(census_sig_kernel, dim3(cdiv((int64_t)Cimg * HW, 256)), dim3(256), 0, st, x0, s0, mk, Cimg, H, W);
+	hipLaunchKernelGGL(census_sig_kernel, dim3(cdiv((int64_t)Cimg * HW, 256)), dim3(256), 0, st, x1, s1, mk, Cimg, H, W);
+	hipLaunchKernelGGL(census_cost_kernel, dim3(cdiv(W, 256), H, D), dim3(256), 0, st, s0, s1, mk, vol, Cimg, D, H, W, direction);
+	return check_launch("census");
+}
+
+// ---- ad, LDS form ---------------------------------------------------------------------------------
+// One block = a 16 x 64 pixel tile of one disparity plane: |x0 - x1(x+d)| for the tile and its 4-pixel frame is
+// staged once in LDS (NaN where the reference's bounds test fails), then every voxel adds its 81 taps in the
+// reference's order (yy outer, xx inner; adcensus.cu:71-84) and divides by the number of in-bounds taps.
+__global__ void __launch_bounds__(256) ad_tile_kernel(const float *__restrict__ x0, const float *__restrict__ x1, float *__restrict__ out,
+                                                      int D, int H, int W, int direction)
+{
+	constexpr int TY = 16, TX = 64, R = 4, TS = TX + 2 * R + 1;
+	__shared__ float A[(TY + 2 * R) * TS];
+	const int bx = blockIdx.x * TX, by = blockIdx.y * TY;
+	const int d = blockIdx.z * direction;
+	const float NANV = __builtin_nanf("");
+	for (int i = threadIdx.x; i < (TY + 2 * R) * (TX + 2 * R); i += 256) {
+		const int ty = i / (TX + 2 * R), tx = i - ty * (TX + 2 * R);
+		const int yy = by + ty - R, xx = bx + tx - R;
+		float v = NANV;
+		if (0 <= xx && xx < W && 0 <= xx + d && xx + d < W && 0 <= yy && yy < H) {
+			const int64_t ind = (int64_t)yy * W + xx;
+			v = fabsf(x0[ind] - x1[ind + d]);
+		}
+		A[ty * TS + tx] = v;
+	}
+	__syncthreads();
+	const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int x = bx + lx;
+	if (x >= W) return;
+	const int64_t HW = (int64_t)H * W;
+	for (int r = wv; r < TY; r += 4) {
+		const int y = by + r;
+		if (y >= H) break;
+		float dist;
+		if (0 <= x + d && x + d < W) {
+			int cnt = 0;
+			dist = 0;
+			const float *base = A + r * TS + lx;
+#pragma unroll
+			for (int j = 0; j < 2 * R + 1; ++j) {
+#pragma unroll
+				for (int k = 0; k < 2 * R + 1; ++k) {
+					const float v = base[j * TS + k];
+					const bool ok = v == v;
+					dist += ok ? v : -0.0f;   // x + -0.0 == x: a skipped tap leaves the accumulator untouched
+					cnt += ok ? 1 : 0;
+				}
+			}
+			dist /= (float)cnt;
+		} else {
+			dist = NANV;
+		}
+		out[(int64_t)blockIdx.z * HW + (int64_t)y * W + x] = dist;
+	}
+}
+
+int ad_tiled(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, hipStream_t st)
+{
+	hipLaunchKernelGGL(ad_tile_kernel, dim3(cdiv(W, 64), cdiv(H, 16), D), dim3(256), 0, st, x0, x1, vol, D, H, W, direction);
+	return check_launch("ad");
 }
 
 }  // namespace mc

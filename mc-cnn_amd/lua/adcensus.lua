@@ -26,6 +26,9 @@ int mc_fill_nan(float *p, int64_t n, void *stream);
 int mc_stereo_join(const float *featL, const float *featR, float *volL, float *volR, int C, int D, int H, int W, void *stream);
 int mc_ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, void *stream);
 int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, void *stream);
+size_t mc_census_scratch_bytes(int Cimg, int H, int W);
+int mc_census_ws(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction,
+                 void *scratch, size_t scratch_bytes, void *stream);
 int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream);
 int mc_cross(const float *img, float *arms, int H, int W, int L1, float tau1, void *stream);
 int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction, void *stream);
@@ -76,9 +79,14 @@ function adcensus.ad(x0, x1, out, direction)                 -- adcensus.cu:95-1
    check(lib.mc_ad(ptr(x0, 'ad'), ptr(x1, 'ad'), ptr(out, 'ad'), out:size(2), out:size(3), out:size(4), direction, nil), 'ad')
 end
 
-function adcensus.census(x0, x1, out, direction)             -- adcensus.cu:155-175
-   check(lib.mc_census(ptr(x0, 'census'), ptr(x1, 'census'), ptr(out, 'census'), x0:size(2),
-                       out:size(2), out:size(3), out:size(4), direction, nil), 'census')
+-- adcensus.census, adcensus.cu:155-175, on the signature kernels (mc_census_ws); scratch kept like cbca's below
+local census_scratch = torch.CudaTensor()
+function adcensus.census(x0, x1, out, direction)
+   local C, D, H, W = x0:size(2), out:size(2), out:size(3), out:size(4)
+   local need = tonumber(lib.mc_census_scratch_bytes(C, H, W))
+   if census_scratch:nElement() * 4 < need then census_scratch:resize(math.ceil(need / 4)) end
+   check(lib.mc_census_ws(ptr(x0, 'census'), ptr(x1, 'census'), ptr(out, 'census'), C, D, H, W, direction,
+                          census_scratch:data(), census_scratch:nElement() * 4, nil), 'census')
 end
 
 function adcensus.StereoJoin(input_L, input_R, output_L, output_R)   -- adcensus.cu:1479-1498

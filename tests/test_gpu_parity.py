@@ -52,7 +52,23 @@ def test_ad_census(mc, oracle, H, W, D, direction):
     c0 = np.stack([x0, x1 * 0.5])
     c1 = np.stack([x1, x0 * 2.0])
     mc.adcensus.census(dev(c0)[None], dev(c1)[None], out, direction)
-    assert_same(host(out), oracle.census(c0, c1, D, direction), "census")
+    assert_same(host(out), oracle.census(c0, c1, D, direction), "census (signatures, mc_census_ws)")
+    mc.adcensus.census_reference_shaped(dev(c0)[None], dev(c1)[None], out, direction)
+    assert_same(host(out), oracle.census(c0, c1, D, direction), "census (mc_census)")
+
+
+@pytest.mark.parametrize("H,W,D", [(37, 150, 40), (5, 9, 12), (20, 70, 80)])
+@pytest.mark.parametrize("direction", [-1, 1])
+def test_ad_census_ties_and_borders(mc, oracle, H, W, D, direction):
+    """Quantised images (many equal intensities: `<` ties), windows larger than the image, W < D."""
+    rng = np.random.default_rng(H * W)
+    x0 = rng.integers(0, 4, (H, W)).astype(np.float32)
+    x1 = rng.integers(0, 4, (H, W)).astype(np.float32)
+    out = torch.empty((1, D, H, W), device="cuda")
+    mc.adcensus.ad(dev(x0), dev(x1), out, direction)
+    assert_same(host(out), oracle.ad(x0, x1, D, direction), "ad")
+    mc.adcensus.census(dev(x0)[None, None], dev(x1)[None, None], out, direction)
+    assert_same(host(out), oracle.census(x0[None], x1[None], D, direction), "census")
 
 
 @pytest.mark.parametrize("H,W", [(24, 40), (17, 33), (40, 9), (1, 50), (30, 1)])
