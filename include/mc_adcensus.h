@@ -71,6 +71,18 @@ size_t mc_census_scratch_bytes(int Cimg, int H, int W);
 int mc_census_ws(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W,
                  int direction, void *scratch, size_t scratch_bytes, void *stream);
 
+/* Accurate architecture (arch slow), main.lua:958-983: for every pixel x and disparity d with x-d >= 0 the stack
+ * net_te2 (main.lua:688-695: nn.SpatialConvolution1_fw layers = addmm + bias, SpatialConvolution1_fw.lua:11-31, ReLU
+ * between, Sigmoid at the end) is applied to concat(featL[:,y,x], featR[:,y,x-d]); the result goes to volL[d,y,x] and
+ * volR[d,y,x-d] (what the reference computes in two passes, one per direction).  Other voxels keep the caller's fill.
+ *   weights[l]: DEVICE pointer to layer l's (out,in) row-major matrix, biases[l]: (out); the two arrays themselves are
+ *   HOST arrays of n_layers device pointers; layer_out[l] = out width: 384 for all but the last, 1 for the last;
+ *   layer 0 has in = 2*C.  fp32 on the matrix cores; parity by tolerance (the reference's GEMM order is cuBLAS's). */
+size_t mc_fc_stack_workspace_bytes(int C, int n_layers, int H, int W);
+int mc_fc_stack(const float *featL, const float *featR, int C, int H, int W, int D,
+                const float *const *weights, const float *const *biases, const int *layer_out, int n_layers,
+                float *volL, float *volR, void *workspace, size_t workspace_bytes, void *stream);
+
 /* fix_border(net, vol, direction), main.lua:922-927: n = (window-1)/2 columns. */
 int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream);
 

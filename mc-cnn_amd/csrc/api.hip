@@ -39,6 +39,9 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
                      int direction, hipStream_t st);
 int cbca_tiled(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
                hipStream_t st);
+size_t fc_workspace_bytes(int C, int n_hidden, int H, int W);
+int fc_stack(const float *featL, const float *featR, int C, int H, int W, int D, const float *const *weights,
+             const float *const *biases, int n_layers, float *volL, float *volR, void *workspace, hipStream_t st);
 size_t sgm_maps_bytes(int H, int W);
 int sgm_prep(const float *x0, const float *x1, void *maps, int H, int W, float tau_so, hipStream_t st);
 int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2], float *const disp[2],
@@ -432,6 +435,31 @@ int mc_census_ws(const float *x0, const float *x1, float *vol, int Cimg, int D, 
 	           census_scratch_bytes(Cimg, H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_census_ws: scratch must be 4-byte aligned");
 	return census_sig(x0, x1, vol, scratch, Cimg, D, H, W, direction, as_stream(stream));
+}
+
+size_t mc_fc_stack_workspace_bytes(int C, int n_layers, int H, int W)
+{
+	if (C < 1 || n_layers < 2 || n_layers > 8 || H < 1 || W < 1) return 0;
+	return fc_workspace_bytes(C, n_layers - 2, H, W);
+}
+
+int mc_fc_stack(const float *featL, const float *featR, int C, int H, int W, int D, const float *const *weights,
+                const float *const *biases, const int *layer_out, int n_layers, float *volL, float *volR, void *workspace,
+                size_t workspace_bytes, void *stream)
+{
+	MC_REQUIRE(featL && featR && weights && biases && layer_out && volL && volR && workspace, "mc_fc_stack: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W) && C >= 1, "mc_fc_stack: bad dims");
+	MC_REQUIRE(n_layers >= 2 && n_layers <= 8, "mc_fc_stack: 2..8 layers supported");
+	for (int l = 0; l < n_layers - 1; ++l)
+		MC_REQUIRE(layer_out[l] == 384, "mc_fc_stack: hidden width %d not supported (nh2 = 384 in every preset, main.lua:77,124)",
+		           layer_out[l]);
+	MC_REQUIRE(layer_out[n_layers - 1] == 1, "mc_fc_stack: the last layer must have one output");
+	for (int l = 0; l < n_layers; ++l) MC_REQUIRE(weights[l] && biases[l], "mc_fc_stack: null layer %d", l);
+	MC_REQUIRE(workspace_bytes >= fc_workspace_bytes(C, n_layers - 2, H, W), "mc_fc_stack: workspace %zu < %zu bytes",
+	           workspace_bytes, fc_workspace_bytes(C, n_layers - 2, H, W));
+	MC_REQUIRE((uintptr_t)workspace % 16 == 0, "mc_fc_stack: workspace must be 16-byte aligned");
+	MC_REQUIRE((int64_t)((H + 7) / 8) * ((W + 95) / 96) * D * 8 < ((int64_t)1 << 31), "mc_fc_stack: problem too large for one launch");
+	return fc_stack(featL, featR, C, H, W, D, weights, biases, n_layers, volL, volR, workspace, as_stream(stream));
 }
 
 int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream)

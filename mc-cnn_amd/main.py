@@ -71,6 +71,9 @@ def parse(argv):
     return dataset, arch, opt, prm
 
 
+FC_SHAPES = {"kitti": (4, 384), "kitti2015": (4, 384), "mb": (3, 384)}  # (l2, nh2), main.lua:76-77, 123-124
+
+
 def load_net(net_fname, dataset, arch, n_input_plane=1):
     """[(w, b)] of the feature net: from an .npz, or seeded random (`random:<seed>`)."""
     l1, fm = NET_SHAPES[(dataset, arch)]
@@ -85,6 +88,45 @@ def load_net(net_fname, dataset, arch, n_input_plane=1):
         return layers
     z = np.load(net_fname)
     return [(z["w%d" % (i + 1)].astype(np.float32), z["b%d" % (i + 1)].astype(np.float32)) for i in range(l1)]
+
+
+def load_fc(net_fname, dataset):
+    """[(w (out,in), b (out))] of net_te2 (arch slow, main.lua:688-695): from an .npz (fw1,fb1,...) or seeded random."""
+    l1, fm = NET_SHAPES[(dataset, "slow")]
+    l2, nh2 = FC_SHAPES[dataset]
+    dims = [2 * fm] + [nh2] * l2 + [1]
+    if net_fname.startswith("random:"):
+        rng = np.random.default_rng(int(net_fname.split(":")[1]) + 1)
+        out = []
+        for i in range(len(dims) - 1):
+            bound = (1.0 if i < len(dims) - 2 else 6.0) / np.sqrt(dims[i])
+            out.append((rng.uniform(-bound, bound, (dims[i + 1], dims[i])).astype(np.float32),
+                        rng.uniform(-bound, bound, (dims[i + 1],)).astype(np.float32)))
+        return out
+    z = np.load(net_fname)
+    return [(z["fw%d" % (i + 1)].astype(np.float32), z["fb%d" % (i + 1)].astype(np.float32)) for i in range(len(dims) - 1)]
+
+
+def features_slow(x_batch, layers):
+    """forward_free(net_te, x_batch) for arch slow (main.lua:681-686): l1 x [3x3 conv, pad 1, ReLU]."""
+    import torch
+    import torch.nn.functional as F
+    h = x_batch
+    for w, b in layers:
+        h = F.relu(F.conv2d(h, torch.from_numpy(w).to(h.device), torch.from_numpy(b).to(h.device), padding=1))
+    return h.contiguous()
+
+
+def raw_volumes_slow(feat, fc_layers, disp_max, border_n):
+    """main.lua:958-983: the FC stack for every (pixel, disparity) -> NaN-filled volumes, then fix_border."""
+    import torch
+    from . import adcensus
+    from .fc import fc_cost_volumes
+    dl = [(torch.from_numpy(w).to(feat.device), torch.from_numpy(b).to(feat.device)) for w, b in fc_layers]
+    vl, vr = fc_cost_volumes(feat, dl, disp_max)
+    adcensus.fix_border(vl, border_n, -1)
+    adcensus.fix_border(vr, border_n, 1)
+    return vl, vr
 
 
 def features_fast(x_batch, layers):
@@ -108,23 +150,30 @@ def main(argv=None):
     dataset, arch, opt, prm = parse(list(sys.argv[1:] if argv is None else argv))
     import torch
     from .predict import Workspace, stereo_predict_fused
-    if arch != "fast":
-        raise SystemExit("main.py: -a %s is wired for arch fast (the accurate net's FC stack is SURVEY 8(f-1)); use the "
-                         "library entry points with raw volumes for arch %s" % (opt.a, arch))
+    if arch not in ("fast", "slow"):
+        raise SystemExit("main.py: -a %s is wired for arch fast and slow; arch %s goes through the library entry points "
+                         "(adcensus.ad / adcensus.census + stereo_predict_fused(raw=...))" % (opt.a, arch))
     dev = torch.device("cuda", opt.gpu - 1)
     torch.cuda.set_device(dev)
     layers = load_net(opt.net_fname, dataset, arch)
+    fc_layers = load_fc(opt.net_fname, dataset) if arch == "slow" else None
     prm["border_n"] = len(layers)  # (1 + l1*(3-1) - 1) / 2, main.lua:382-391,923
+
+    def run(x_batch, D, workspace=None, want_volumes=False):
+        if arch == "fast":
+            return stereo_predict_fused(x_batch, prm, D, feat=features_fast(x_batch, layers), workspace=workspace,
+                                        want_volumes=want_volumes)
+        raw = raw_volumes_slow(features_slow(x_batch, layers), fc_layers, D, prm["border_n"])
+        return stereo_predict_fused(x_batch, prm, D, raw=raw, workspace=workspace, want_volumes=want_volumes)
     if opt.a == "time":  # main.lua:1140-1167
         H, W, D = (240, 320, 32) if opt.tiny else ((350, 1242, 228) if dataset != "mb" else (1000, 1500, 200))
         x_batch = torch.empty((2, 1, H, W), dtype=torch.float32, device=dev).normal_()
         ws = Workspace(prm, D, H, W, dev)
         best = float("inf")
-        for _ in range(30):
+        for _ in range(30 if arch == "fast" else 3):  # main.lua:1152
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            feat = features_fast(x_batch, layers)
-            stereo_predict_fused(x_batch, prm, D, feat=feat, workspace=ws)
+            run(x_batch, D, workspace=ws)
             torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
         print(best)
@@ -135,8 +184,7 @@ def main(argv=None):
         x0, x1 = rgb2y(x0), rgb2y(x1)
     D = opt.disp_max
     x_batch = torch.from_numpy(np.stack([normalize(x0), normalize(x1)])).to(dev)  # (2,1,H,W)
-    feat = features_fast(x_batch, layers)
-    res = stereo_predict_fused(x_batch, prm, D, feat=feat, want_volumes=True)
+    res = run(x_batch, D, want_volumes=True)
     torch.cuda.synchronize()
     H, W = x_batch.shape[2:]
     for name, key in (("right", "volR"), ("left", "volL")):  # main.lua:954-955 writes right.bin first

@@ -218,6 +218,26 @@ def normalize_forward(x):
     return out
 
 
+def fc_stack(featL, featR, D, layers):
+    """layers: [(W (out,in), b (out))...]; returns NaN-filled (D,H,W) left / right volumes with the valid voxels set."""
+    featL, featR = _a(featL), _a(featR)
+    Cn, H, W = featL.shape
+    ws = [_a(w) for w, _ in layers]
+    bs = [_a(b) for _, b in layers]
+    n = len(layers)
+    wp = (_f32p * n)(*[_p(w) for w in ws])
+    bp = (_f32p * n)(*[_p(b) for b in bs])
+    widths = (C.c_int * n)(*[w.shape[0] for w in ws])
+    vl = np.full((D, H, W), np.nan, np.float32)
+    vr = np.full((D, H, W), np.nan, np.float32)
+    fn = lib().oracle_fc_stack
+    fn.restype = None
+    fn.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_f32p), C.POINTER(_f32p), C.POINTER(C.c_int),
+                   C.c_int, _f32p, _f32p]
+    fn(_p(featL), _p(featR), Cn, H, W, D, wp, bp, widths, n, _p(vl), _p(vr))
+    return vl, vr
+
+
 def make_params(d):
     p = OracleParams()
     term = {"": 0, "cnn": 1, "cbca1": 2, "sgm": 3, "cbca2": 4, "occlusion": 5, "mismatch": 6,

@@ -752,4 +752,60 @@ done:
 	return rc;
 }
 
+/*
+ * Accurate architecture, main.lua:958-983 with net_te2 = main.lua:688-695 and nn.SpatialConvolution1_fw
+ * (SpatialConvolution1_fw.lua:11-31: output = W * input (addmm, beta 0), then + bias), cudnn.ReLU in between and
+ * cudnn.Sigmoid at the end.  For each direction and each d the reference builds the (2C, H, W-d) concatenation of
+ * L[:, :, d..W-1] and R[:, :, 0..W-1-d], runs the stack on every column and copies the (H, W-d) result into
+ * vol[d][:, d..W-1] (direction -1) / vol[d][:, 0..W-1-d] (direction +1); other entries keep the caller's NaN fill.
+ * The GEMM summation order of cuBLAS and cudnn's sigmoid are third-party and unpinned: this restatement sums with k
+ * ascending in fp32 and uses 1/(1+expf(-x)); parity for this operator is by tolerance (1e-4), see DESIGN.md.
+ * weights[l]: (out_l, in_l) row-major, in_0 = 2C.
+ */
+API void oracle_fc_stack(const float *featL, const float *featR, int C, int H, int W, int D,
+                         const float *const *weights, const float *const *biases, const int *widths, int n_layers,
+                         float *volL, float *volR)
+{
+	const int64_t HW = (int64_t)H * W;
+	int maxw = 2 * C;
+	for (int l = 0; l < n_layers; l++) maxw = imax(maxw, widths[l]);
+	for (int dirk = 0; dirk < 2; dirk++) {
+		const int direction = dirk == 0 ? 1 : -1; /* main.lua:954-955 */
+		float *vol = direction == -1 ? volL : volR;
+#pragma omp parallel
+		{
+			float *cur = (float *)malloc(sizeof(float) * maxw);
+			float *nxt = (float *)malloc(sizeof(float) * maxw);
+#pragma omp for collapse(2) schedule(dynamic, 4)
+			for (int d = 0; d < D; d++) {
+				for (int y = 0; y < H; y++) {
+					for (int j = 0; j < W - d; j++) { /* column j of the (2C, H, W-d) input: left pixel d+j, right pixel j */
+						for (int c = 0; c < C; c++) {
+							cur[c] = featL[c * HW + (int64_t)y * W + d + j];
+							cur[C + c] = featR[c * HW + (int64_t)y * W + j];
+						}
+						int in = 2 * C;
+						for (int l = 0; l < n_layers; l++) {
+							const int out = widths[l];
+							for (int n = 0; n < out; n++) {
+								float s = 0.0f;
+								for (int k = 0; k < in; k++) s += weights[l][(int64_t)n * in + k] * cur[k];
+								s = s + biases[l][n];
+								if (l < n_layers - 1) s = s > 0.0f ? s : 0.0f;         /* cudnn.ReLU */
+								else s = 1.0f / (1.0f + expf(-s));                      /* cudnn.Sigmoid */
+								nxt[n] = s;
+							}
+							float *t = cur; cur = nxt; nxt = t;
+							in = out;
+						}
+						const int xcol = direction == -1 ? d + j : j;
+						vol[(int64_t)d * HW + (int64_t)y * W + xcol] = cur[0];
+					}
+				}
+			}
+			free(cur); free(nxt);
+		}
+	}
+}
+
 API int oracle_version(void) { return 1; }
