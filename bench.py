@@ -33,6 +33,8 @@ CONFIGS = {
     "kitti_fast": ("kitti_fast", 370, 1226, 228, 64, "KITTI 2012 fast, 370x1226 disp_max=228"),
     "kitti_slow": ("kitti_slow", 370, 1226, 228, 0, "KITTI 2012 accurate (from raw volumes), 370x1226 disp_max=228"),
     "mb_slow": ("mb_slow", 1000, 1500, 256, 0, "Middlebury-size accurate (from raw volumes), 1000x1500 disp_max=256"),
+    # accurate net end to end from features: FC stack (fp32 MFMA) -> fix_border -> CBCA -> SGM -> post
+    "kitti_slow_fc": ("kitti_slow", 370, 1226, 228, -112, "KITTI 2012 accurate (slow net) from conv features, 370x1226 disp_max=228"),
     "tiny": ("kitti_fast", 48, 160, 32, 16, "tiny plumbing case"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -57,7 +59,16 @@ def make_inputs(cfg, rank, device):
     x0, x1 = smooth_pair(H, W, D, seed=1234 + rank)
     xb = torch.from_numpy(np.stack([x0, x1])[:, None]).to(device)
     host = dict(x0=x0, x1=x1)
-    if C:
+    if C < 0:  # accurate net: non-negative (post-ReLU) features + a seeded FC stack (no trained nets are available)
+        from mc_cnn_amd.main import load_fc
+        rng = np.random.default_rng(42 + rank)
+        f = np.maximum(rng.standard_normal((2, -C, H, W)), 0).astype(np.float32)
+        host["feat"] = f
+        fcl = load_fc("random:%d" % (7 + rank), "kitti")
+        kw = dict(fc_feat=torch.from_numpy(f).to(device),
+                  fc_layers=[(torch.from_numpy(w).to(device), torch.from_numpy(b).to(device)) for w, b in fcl])
+        host["fc_layers"] = fcl
+    elif C:
         f = features(C, H, W, seed=42 + rank)
         host["feat"] = f
         kw = dict(feat=torch.from_numpy(f).to(device))
@@ -157,10 +168,29 @@ def main():
     out = torch.empty((1, 1, H, W), dtype=torch.float32, device=device)
     gathered = torch.empty((world, H, W), dtype=torch.float32, device=device) if world > 1 else None
 
-    def step():
-        mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, **kw)
+    fc_ws = None
+    if "fc_feat" in kw:
+        from mc_cnn_amd.fc import fc_cost_volumes
+        need = mc._lib.lib.mc_fc_stack_workspace_bytes(-C, len(kw["fc_layers"]), H, W)
+        fc_ws = torch.empty(need + 16, dtype=torch.uint8, device=device)
+
+    def cost_volume():
+        """the accurate net's cost-volume stage: FC stack + fix_border (main.lua:958-983)"""
+        vl, vr = fc_cost_volumes(kw["fc_feat"], kw["fc_layers"], D, workspace=fc_ws)
+        mc.adcensus.fix_border(vl, prm["border_n"], -1)
+        mc.adcensus.fix_border(vr, prm["border_n"], 1)
+        return vl, vr
+
+    def step(timed=False):
+        if fc_ws is not None:
+            return mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, raw=cost_volume(), timed=timed)
+        return mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, timed=timed, **kw)
+
+    def step_untimed():
+        step()
         if world > 1:  # the path's only exchange: finished disparity maps (H*W*4 B per GPU) over xGMI
             dist.all_gather_into_tensor(gathered, out.view(1, H, W))
+
 
     def sync():
         if world > 1:
@@ -168,11 +198,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        step_untimed()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step_untimed()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -189,11 +219,18 @@ def main():
         reps = max(3, min(10, args.steps))
         acc = {}
         for _ in range(reps):
-            r = mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, timed=True, **kw)
+            if fc_ws is not None:  # the FC stack runs before mc_predict: time it with events on the same stream
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                cost_volume()
+                e1.record()
+                torch.cuda.synchronize()
+                acc["fc_stack"] = acc.get("fc_stack", 0.0) + e0.elapsed_time(e1) / reps
+            r = step(timed=True)
             for k, v in r["stage_ms"].items():
                 acc[k] = acc.get(k, 0.0) + v / reps
         stage = {k: round(v, 4) for k, v in acc.items() if k != "_"}
-        ab = algorithmic_bytes(prm, H, W, D, C)
+        ab = algorithmic_bytes(prm, H, W, D, max(C, 0))
         dom = "cbca" if ab["cbca"] > ab["sgm"] else "sgm"
         n_launch = {"sgm": 3 * prm["sgm_i"], "cbca": 2 * (prm["cbca_i1"] + prm["cbca_i2"])}[dom]
         achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9 if acc[dom] > 0 else 0.0
@@ -209,10 +246,25 @@ def main():
                     avg_launch_ms=round(acc[dom] / n_launch, 4),
                     pipeline_frac=round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
+    if rank == 0 and fc_ws is not None and roof is not None:
+        # the accurate net's dominant kernel is the FC stack: a dense fp32 GEMM chain on the matrix cores
+        dims = [w.shape[1] for w, _ in kw["fc_layers"]] + [1]
+        vox = sum(max(0, W - d) for d in range(D)) * H
+        flop = vox * 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))  # the reference's flops (main.lua:958-983)
+        tf = flop / (acc["fc_stack"] * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="fc_stack_kernel (+ fc_project_kernel): both volumes from one pass", achieved=round(tf, 1),
+                    peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4), traffic=None, launches_per_step=1,
+                    algorithmic_flops_per_launch=flop, avg_launch_ms=round(acc["fc_stack"], 3),
+                    note="fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense peak); layer 1 is evaluated as two per-pixel "
+                         "projections, so the executed flops are 16 % below the reference's count used here")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        rows = args.cpu_rows or {"kitti_fast": 370, "kitti_slow": 370, "mb_slow": 8, "tiny": 48}[args.config]
-        cpu = cpu_baseline(cfg, host, rows)
+        if args.config == "kitti_slow_fc":
+            cpu = None  # the oracle's FC stack is a scalar triple loop (hours at this size); see kitti_slow for the pipeline's CPU baseline
+        else:
+            rows = args.cpu_rows or {"kitti_fast": 370, "kitti_slow": 370, "mb_slow": 8, "tiny": 48}[args.config]
+            cpu = cpu_baseline(cfg, host, rows)
 
     refgpu = None
     if rank == 0 and world == 1 and not args.no_ref_gpu and args.config in ("kitti_fast", "kitti_slow", "tiny"):
@@ -224,7 +276,7 @@ def main():
             "value": round(value, 1), "unit": "MPix-disp/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg_name, "H": H, "W": W, "disp_max": D, "feature_channels": C,
+            "config": {"workload": cfg_name, "H": H, "W": W, "disp_max": D, "feature_channels": abs(C),
                        "params": preset_name, "pairs_per_step": world, "parallelism": "one pair per GPU",
                        "end_to_end_ms_per_pair": round(ms_per_step, 4)},
             "stage_ms": stage, "roofline": roof, "cpu_baseline": cpu, "reference_on_gpu": refgpu,
