@@ -154,11 +154,17 @@ def main():
         print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" %
               (args.gpus, args.gpus), file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MC_BENCH_ONE_GPU=1 (plumbing check on a 1-GPU box only): every rank uses cuda:0 and the collectives run over gloo
+    one_gpu = os.environ.get("MC_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     cfg = CONFIGS[args.config]
     preset_name, H, W, D, C, cfg_name = cfg
@@ -189,7 +195,11 @@ def main():
     def step_untimed():
         step()
         if world > 1:  # the path's only exchange: finished disparity maps (H*W*4 B per GPU) over xGMI
-            dist.all_gather_into_tensor(gathered, out.view(1, H, W))
+            if one_gpu:
+                parts = [torch.empty((1, H, W)) for _ in range(world)]
+                dist.all_gather(parts, out.view(1, H, W).cpu())
+            else:
+                dist.all_gather_into_tensor(gathered, out.view(1, H, W))
 
 
     def sync():
@@ -206,7 +216,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
