@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) cbca_tile_kernel(const CbcaArgs A)
 	const int per = (ntiles + 7) >> 3;
 	const int t = (b & 7) * per + (b >> 3);
 	if (t >= ntiles) return;
-	const int by = t % gy, bx = (t / gy) % gx, bz = t / (gy * gx);
+	const int bx = t % gx, by = (t / gx) % gy, bz = t / (gy * gx);
 	const int x0 = bx * TXO, y0 = by * CB_TY;
 	const int d0 = bz * A.nd;
 	const int d1 = min(D, d0 + A.nd);
@@ -313,12 +313,254 @@ __global__ void __launch_bounds__(256) cbca_tile_kernel(const CbcaArgs A)
 	}
 }
 
-size_t cbca_scratch_bytes(int H, int W) { return ((size_t)2 * H * W * sizeof(uint32_t) + 4 + 255) & ~(size_t)255; }
 
-// scratch = [p0 (H*W) | p1 (H*W) | overflow flag]
+// =====================================================================================================
+// cbca v7: wave-autonomous strips
+// =====================================================================================================
+// One wave owns one disparity plane, a strip of 256 staged columns (4 per lane, dwordx4 rows of 1 KB) and RB output
+// rows, and walks the strip top to bottom.  Rows are loaded PF steps ahead into registers (volume row, the left image's
+// packed lengths, the right image's lengths shifted by d), committed to a wave-private ring of 4 rows in LDS (volume
+// values and the byte-wise minimum lengths) and the output row one row behind the newest committed one is produced:
+// no block barrier anywhere, LDS traffic is dwordx4, and a lane produces FOUR horizontally adjacent outputs -- columns
+// 4*lane+2 .. 4*lane+5 of the frame, so that the 252 outputs of a strip are 63 full dwordx4 stores and the window
+// 4*lane .. 4*lane+7 of a lane is two aligned LDS reads per row.  The minimal 3x3 support is computed for all four
+// outputs unconditionally (nine additions in the reference's order each).  Outputs with a larger support are few and
+// scattered on textured images, so they are COMPACTED: their frame columns go to a small per-wave list, lane i then
+// re-runs the reference's loop (rows ascending, x ascending, one accumulator) for list entry i -- out of the ring where
+// the support lies inside rows y-2..y+1 / the strip's 256 columns and out of global memory otherwise -- and patches
+// the row of results in LDS before it is stored.
+constexpr int CS_RING = 4;
+constexpr int CS_COLS = 256;
+constexpr int CS_STEP = 252;   // output columns per strip
+constexpr int CS_UP = 1;       // rows staged above the first output row
+constexpr int CS_LA = 1;       // rows committed below the current output row
+constexpr int CS_PAD = 1024;   // words of padding around p0 / p1 in the scratch (shifted dwordx4 reads may start outside)
+
+typedef unsigned cb_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned cb_u2 __attribute__((ext_vector_type(2)));
+typedef float cb_f4 __attribute__((ext_vector_type(4)));
+typedef float cb_f2 __attribute__((ext_vector_type(2)));
+
+template <int PF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) cbca_strip_kernel(const CbcaArgs A)
+{
+	__shared__ float Vring[4][CS_RING * CS_COLS];
+	__shared__ cb_u32 Mring[4][CS_RING * CS_COLS];
+	__shared__ float Rrow[4][CS_COLS];          // results of the current row (patched by the compacted pass)
+	__shared__ unsigned short Clist[4][CS_COLS];  // frame columns of the outputs that need the general loop
+	if (A.overflow && *A.overflow) return;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane descriptors stay in SGPRs
+	float *__restrict__ V = Vring[wv];
+	cb_u32 *__restrict__ M = Mring[wv];
+	float *__restrict__ R = Rrow[wv];
+	unsigned short *__restrict__ CL = Clist[wv];
+	const int H = A.H, W = A.W, direction = A.direction;
+	const int HWi = H * W;
+	// wave -> (region, d).  The four waves of a block take four consecutive disparities of ONE region (strip x row
+	// chunk) and the blocks of an XCD (blockIdx % 8) walk all disparity groups of a region before the next region:
+	// the packed lengths of a region (left: identical for every d, right: windows shifted by d) are then fetched
+	// from HBM once per XCD and served by its L2 for the other D - 1 planes.
+	const int dgroups = (A.D + 3) >> 2;
+	const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
+	const int region = (kb / dgroups) * 8 + xcd;
+	const int d = (kb % dgroups) * 4 + wv;
+	if (region >= A.gx * A.gy || d >= A.D) return;
+	const int cx = region % A.gx, cy = region / A.gx;
+	const int sh = d * direction;
+	const int xs = cx * CS_STEP - 2 + 4 * lane;   // image column of this lane's first staged column
+	const int xo = xs + 2;                        // image column of this lane's first output
+	const int y0 = cy * A.nd, y1 = min(H, y0 + A.nd);   // nd = output rows per strip here
+	const int ra = y0 - CS_UP;                    // first staged row (rows outside the image: loaded as zeros, never used)
+	const int plane_bytes = HWi * 4;
+	const cb_u32 OOB = 0x80000000u;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
+	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
+	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
+	const bool full_in = xs >= 0 && xs + 3 < W;                 // all four staged columns exist: one dwordx4 inside the row
+	const bool full_out = lane < 63 && xo + 3 < W;
+	const bool any_out = lane < 63 && xo < W;
+	// per output: bit j = output column exists and its shifted partner is inside the image (adcensus.cu:353-354)
+	cb_u32 inr_mask = 0, valid_mask = 0;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int x = xo + j;
+		if (lane < 63 && x < W) valid_mask |= 1u << j;
+		if (x + sh >= 0 && x + sh < W) inr_mask |= 1u << j;
+	}
+
+	struct Stage { cb_u4 v, a, b; };
+	auto fetch = [&](Stage &st, int r) {  // row r of the plane -> registers (rows outside the image: zeros)
+		const bool rok = r >= 0 && r < H;
+		const int base = r * W + xs;
+		if (full_in) {
+			st.v = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)base * 4u : OOB, 0, 0);
+		} else {  // strip edges: per column
+			cb_u32 t[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_raw_buffer_load_b32(rv, (rok && xs + k >= 0 && xs + k < W) ? (cb_u32)(base + k) * 4u : OOB, 0, 0);
+			st.v = cb_u4{t[0], t[1], t[2], t[3]};
+		}
+		// lengths: the padded scratch makes any in-row start readable; columns outside the image / the shifted range
+		// hold values that are never used
+		st.a = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
+		st.b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
+	};
+	auto commit = [&](const Stage &st, int r) {
+		const int o = (r & (CS_RING - 1)) * CS_COLS + 4 * lane;
+		*(cb_u4 *)(V + o) = st.v;
+		cb_u4 m;
+		m.x = bytemin4(st.a.x, st.b.x); m.y = bytemin4(st.a.y, st.b.y); m.z = bytemin4(st.a.z, st.b.z); m.w = bytemin4(st.a.w, st.b.w);
+		*(cb_u4 *)(M + o) = m;
+	};
+
+	// the reference's loop for the output in frame column c of row yo (any support)
+	auto general = [&](int yo, int c) -> float {
+		const int x = cx * CS_STEP - 2 + c;
+		const cb_u32 mc = M[(yo & (CS_RING - 1)) * CS_COLS + c];
+		const int u = (int)((mc >> 16) & 0xff), dn = (int)(mc >> 24);
+		const int lo_row = max(max(ra, 0), yo + CS_LA - (CS_RING - 1)), hi_row = min(H - 1, yo + CS_LA);
+		float sum = 0;
+		int cnt = 0;
+		for (int q = yo - u; q <= yo + dn; ++q) {
+			const bool row_in = q >= lo_row && q <= hi_row;
+			const int rowo = (q & (CS_RING - 1)) * CS_COLS;
+			cb_u32 mm;
+			if (row_in) mm = M[rowo + c];
+			else {
+				const int g = q * W + x;
+				mm = bytemin4(A.p0[g], A.p1[g + sh]);
+			}
+			const int l = (int)(mm & 0xff), rg = (int)((mm >> 8) & 0xff);
+			const int n = l + rg + 1;
+			if (row_in && c - l >= 0 && c + rg < CS_COLS) {
+				const float *row = V + rowo + c - l;
+				int k = 0;
+				for (; k + 4 <= n; k += 4) {
+					const float v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3];
+					sum += v0; sum += v1; sum += v2; sum += v3;
+				}
+				if (k < n) {
+					const float v0 = row[k];
+					const float v1 = row[min(k + 1, n - 1)], v2 = row[min(k + 2, n - 1)];
+					sum += v0;
+					if (k + 1 < n) sum += v1;
+					if (k + 2 < n) sum += v2;
+				}
+			} else {  // run leaves the staged frame: from global memory, same order
+				const float *row = A.vin + (size_t)d * HWi + q * W + x - l;
+				for (int k = 0; k < n; ++k) sum += row[k];
+			}
+			cnt += n;
+		}
+		return sum / (float)cnt;
+	};
+
+	auto output = [&](int yo) {
+		const int s0 = (yo & (CS_RING - 1)) * CS_COLS, sm = ((yo - 1) & (CS_RING - 1)) * CS_COLS, sp = ((yo + 1) & (CS_RING - 1)) * CS_COLS;
+		const int c0 = 4 * lane;                       // first frame column of this lane's 8-wide window
+		const int c1 = lane < 63 ? c0 + 4 : c0;        // (lane 63 has no outputs; keep its reads inside the row)
+		cb_u32 mo[4], mu[4], md[4];
+		{
+			const cb_u2 t0 = *(const cb_u2 *)(M + s0 + c0 + 2), t1 = *(const cb_u2 *)(M + s0 + c1);
+			mo[0] = t0.x; mo[1] = t0.y; mo[2] = t1.x; mo[3] = t1.y;
+			const cb_u2 u0 = *(const cb_u2 *)(M + sm + c0 + 2), u1 = *(const cb_u2 *)(M + sm + c1);
+			mu[0] = u0.x; mu[1] = u0.y; mu[2] = u1.x; mu[3] = u1.y;
+			const cb_u2 d0 = *(const cb_u2 *)(M + sp + c0 + 2), d1 = *(const cb_u2 *)(M + sp + c1);
+			md[0] = d0.x; md[1] = d0.y; md[2] = d1.x; md[3] = d1.y;
+		}
+		float ra_[8], rb_[8], rc_[8];
+		{
+			const cb_f4 a0 = *(const cb_f4 *)(V + sm + c0), a1 = *(const cb_f4 *)(V + sm + c1);
+			const cb_f4 b0 = *(const cb_f4 *)(V + s0 + c0), b1 = *(const cb_f4 *)(V + s0 + c1);
+			const cb_f4 e0 = *(const cb_f4 *)(V + sp + c0), e1 = *(const cb_f4 *)(V + sp + c1);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { ra_[k] = a0[k]; ra_[4 + k] = a1[k]; rb_[k] = b0[k]; rb_[4 + k] = b1[k]; rc_[k] = e0[k]; rc_[4 + k] = e1[k]; }
+		}
+		float res[4];
+		cb_u32 needmask = 0;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			// minimal support <=> own arms all 1 and the rows above / below have left = right = 1 in this column
+			const cb_u32 t = (mo[j] ^ 0x01010101u) | ((((mu[j] ^ 0x0101u) | (md[j] ^ 0x0101u)) & 0xffffu) << 16);
+			float sum = 0;
+			sum += ra_[j + 1]; sum += ra_[j + 2]; sum += ra_[j + 3];
+			sum += rb_[j + 1]; sum += rb_[j + 2]; sum += rb_[j + 3];
+			sum += rc_[j + 1]; sum += rc_[j + 2]; sum += rc_[j + 3];
+			const bool inr = (inr_mask >> j) & 1u;
+			res[j] = (inr && !(A.ablate & 2)) ? sum / 9.0f : rb_[j + 2];
+			if (t != 0) needmask |= 1u << j;
+		}
+		needmask &= inr_mask & valid_mask;
+		if (A.ablate & 1) needmask = 0;
+		if (__any(needmask != 0)) {
+			// compact the (lane, j) pairs that need the general loop into CL[0..n)
+			int n = 0;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const bool nj = (needmask >> j) & 1u;
+				const uint64_t bal = __ballot(nj);
+				const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((cb_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)bal, 0));
+				if (nj) CL[pos] = (unsigned short)(4 * lane + 2 + j);
+				n += __builtin_popcountll(bal);
+			}
+			*(cb_f2 *)(R + c0 + 2) = cb_f2{res[0], res[1]};
+			if (lane < 63) *(cb_f2 *)(R + c0 + 4) = cb_f2{res[2], res[3]};
+			for (int e0 = 0; e0 < n; e0 += 64) {
+				const int e = e0 + lane;
+				if (e < n) {
+					const int c = CL[e];
+					R[c] = general(yo, c);
+				}
+			}
+			const cb_f2 r0 = *(const cb_f2 *)(R + c0 + 2), r1 = *(const cb_f2 *)(R + c1 + (lane < 63 ? 0 : 2));
+			res[0] = r0.x; res[1] = r0.y; res[2] = r1.x; res[3] = r1.y;
+		}
+		const int ob = yo * W + xo;
+		if (full_out) {
+			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
+			                                       ro, (cb_u32)ob * 4u, 0, 0);
+		} else if (any_out) {
+#pragma unroll
+			for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[j]), ro, xo + j < W ? (cb_u32)(ob + j) * 4u : OOB, 0, 0);
+		}
+	};
+
+	Stage st[PF];
+#pragma unroll
+	for (int u = 0; u < PF; ++u) fetch(st[u], ra + u);
+	const int last = y1 - 1 + CS_LA;   // newest row that has to be committed for the last output row
+	for (int g = ra; g <= last; g += PF) {
+#pragma unroll
+		for (int u = 0; u < PF; ++u) {
+			const int r = g + u;
+			commit(st[u], r);
+			fetch(st[u], r + PF);
+			const int yo = r - CS_LA;
+			if (yo >= y0 && yo < y1) output(yo);
+		}
+	}
+}
+
+// scratch = [pad | p0 (H*W) | pad | p1 (H*W) | pad | overflow flag], pad = CS_PAD words
+size_t cbca_scratch_bytes(int H, int W) { return (((size_t)2 * H * W + 3 * CS_PAD + 1) * sizeof(uint32_t) + 255) & ~(size_t)255; }
+
+struct CbcaScratch { uint32_t *p0, *p1, *flag; };
+static CbcaScratch cbca_scratch(const void *scratch, int H, int W)
+{
+	CbcaScratch s;
+	s.p0 = (uint32_t *)scratch + CS_PAD;
+	s.p1 = s.p0 + (size_t)H * W + CS_PAD;
+	s.flag = s.p1 + (size_t)H * W + CS_PAD;
+	return s;
+}
+
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st)
 {
-	uint32_t *p0 = (uint32_t *)scratch, *p1 = p0 + (size_t)H * W, *flag = p1 + (size_t)H * W;
+	const CbcaScratch cs = cbca_scratch(scratch, H, W);
+	uint32_t *p0 = cs.p0, *p1 = cs.p1, *flag = cs.flag;
 	const int64_t HW = (int64_t)H * W;
 	const hipError_t e = hipMemsetAsync(flag, 0, sizeof(uint32_t), st);
 	if (e != hipSuccess) {
@@ -334,7 +576,7 @@ int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, h
 int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
                      int direction, hipStream_t st)
 {
-	const uint32_t *flag = (const uint32_t *)packed + (size_t)2 * H * W;
+	const uint32_t *flag = cbca_scratch(packed, H, W).flag;
 	hipLaunchKernelGGL(cbca_direct_kernel, dim3(cdiv(W, 64), cdiv(H, 4), D), dim3(256), 0, st, x0c, x1c, vin, vout, D, H, W,
 	                   direction, flag);
 	return check_launch("cbca (overflow path)");
@@ -347,14 +589,26 @@ int cbca_tiled(const void *packed, const float *vin, float *vout, int D, int H, 
 	static const int env_nd = [] { const char *e = getenv("MC_CBCA_ND"); return e ? atoi(e) : 0; }();      // tuning aids
 	static const int env_halo = [] { const char *e = getenv("MC_CBCA_HALO"); return e ? atoi(e) : 0; }();
 	CbcaArgs A;
-	A.p0 = (const uint32_t *)packed; A.p1 = A.p0 + (size_t)H * W;
+	const CbcaScratch cs = cbca_scratch(packed, H, W);
+	A.p0 = cs.p0; A.p1 = cs.p1;
 	A.vin = vin; A.vout = vout;
 	A.D = D; A.H = H; A.W = W; A.direction = direction;
 	A.nd = CB_ND;
 	(void)env_nd;
 	static const int env_abl = [] { const char *e = getenv("MC_CBCA_ABLATE"); return e ? atoi(e) : 0; }();
 	A.ablate = env_abl;
-	A.overflow = max_arm < 0 ? A.p1 + (size_t)H * W : nullptr;  // unknown arm bound: honour cbca_pack's flag
+	A.overflow = max_arm < 0 ? cs.flag : nullptr;  // unknown arm bound: honour cbca_pack's flag
+	static const int env_kernel = [] { const char *e = getenv("MC_CBCA_KERNEL"); return e ? atoi(e) : 0; }();  // 1 = tile kernel
+	static const int env_rb = [] { const char *e = getenv("MC_CBCA_RB"); return e ? atoi(e) : 0; }();
+	if (env_kernel != 1) {
+		A.nd = env_rb > 0 ? env_rb : 40;  // output rows per strip
+		A.gx = (int)cdiv(W, CS_STEP); A.gy = (int)cdiv(H, A.nd); A.gz = D;
+		const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(D, 4) * 4;
+		static const int env_pf = [] { const char *e = getenv("MC_CBCA_PF"); return e ? atoi(e) : 0; }();
+		if (env_pf == 2) hipLaunchKernelGGL(cbca_strip_kernel<2>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+		else hipLaunchKernelGGL(cbca_strip_kernel<4>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+		return check_launch("cbca_strip");
+	}
 	// frame width 2 measured best on MI355X for both tight (Middlebury) and looser (KITTI) thresholds; longer arms take
 	// the per-run global path
 	int halo = (max_arm >= 0 && max_arm < 2) ? 1 : 2;
