@@ -329,11 +329,8 @@ __global__ void __launch_bounds__(256) cbca_tile_kernel(const CbcaArgs A)
 // re-runs the reference's loop (rows ascending, x ascending, one accumulator) for list entry i -- out of the ring where
 // the support lies inside rows y-2..y+1 / the strip's 256 columns and out of global memory otherwise -- and patches
 // the row of results in LDS before it is stored.
-constexpr int CS_RING = 4;
 constexpr int CS_COLS = 256;
 constexpr int CS_STEP = 252;   // output columns per strip
-constexpr int CS_UP = 1;       // rows staged above the first output row
-constexpr int CS_LA = 1;       // rows committed below the current output row
 constexpr int CS_PAD = 1024;   // words of padding around p0 / p1 in the scratch (shifted dwordx4 reads may start outside)
 
 typedef unsigned cb_u4 __attribute__((ext_vector_type(4)));
@@ -341,20 +338,23 @@ typedef unsigned cb_u2 __attribute__((ext_vector_type(2)));
 typedef float cb_f4 __attribute__((ext_vector_type(4)));
 typedef float cb_f2 __attribute__((ext_vector_type(2)));
 
-template <int PF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) cbca_strip_kernel(const CbcaArgs A)
+// CS_RING rows per ring, CS_LA rows committed below (and staged above) the current output row
+template <int PF, int CS_RING, int CS_LA>
+__global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 {
+	constexpr int CS_UP = CS_LA;
+	auto slot = [](int r) { return (CS_RING & (CS_RING - 1)) == 0 ? (r & (CS_RING - 1)) : (int)((unsigned)(r + 4 * CS_RING) % (unsigned)CS_RING); };
 	__shared__ float Vring[4][CS_RING * CS_COLS];
 	__shared__ cb_u32 Mring[4][CS_RING * CS_COLS];
 	__shared__ float Rrow[4][CS_COLS];          // results of the current row (patched by the compacted pass)
-	__shared__ unsigned short Clist[4][CS_COLS];  // frame columns of the outputs that need the general loop
+	__shared__ cb_u32 Clist[4][CS_COLS];        // outputs that need the general loop: frame column | up << 16 | down << 24
 	if (A.overflow && *A.overflow) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane descriptors stay in SGPRs
 	float *__restrict__ V = Vring[wv];
 	cb_u32 *__restrict__ M = Mring[wv];
 	float *__restrict__ R = Rrow[wv];
-	unsigned short *__restrict__ CL = Clist[wv];
+	cb_u32 *__restrict__ CL = Clist[wv];
 	const int H = A.H, W = A.W, direction = A.direction;
 	const int HWi = H * W;
 	// wave -> (region, d).  The four waves of a block take four consecutive disparities of ONE region (strip x row
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 		st.b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
 	};
 	auto commit = [&](const Stage &st, int r) {
-		const int o = (r & (CS_RING - 1)) * CS_COLS + 4 * lane;
+		const int o = slot(r) * CS_COLS + 4 * lane;
 		*(cb_u4 *)(V + o) = st.v;
 		cb_u4 m;
 		m.x = bytemin4(st.a.x, st.b.x); m.y = bytemin4(st.a.y, st.b.y); m.z = bytemin4(st.a.z, st.b.z); m.w = bytemin4(st.a.w, st.b.w);
@@ -417,16 +417,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 	};
 
 	// the reference's loop for the output in frame column c of row yo (any support)
-	auto general = [&](int yo, int c) -> float {
+	auto general = [&](int yo, int c, int u, int dn, int lo_row, int hi_row) -> float {
 		const int x = cx * CS_STEP - 2 + c;
-		const cb_u32 mc = M[(yo & (CS_RING - 1)) * CS_COLS + c];
-		const int u = (int)((mc >> 16) & 0xff), dn = (int)(mc >> 24);
-		const int lo_row = max(max(ra, 0), yo + CS_LA - (CS_RING - 1)), hi_row = min(H - 1, yo + CS_LA);
 		float sum = 0;
 		int cnt = 0;
 		for (int q = yo - u; q <= yo + dn; ++q) {
 			const bool row_in = q >= lo_row && q <= hi_row;
-			const int rowo = (q & (CS_RING - 1)) * CS_COLS;
+			const int rowo = slot(q) * CS_COLS;
 			cb_u32 mm;
 			if (row_in) mm = M[rowo + c];
 			else {
@@ -459,7 +456,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 	};
 
 	auto output = [&](int yo) {
-		const int s0 = (yo & (CS_RING - 1)) * CS_COLS, sm = ((yo - 1) & (CS_RING - 1)) * CS_COLS, sp = ((yo + 1) & (CS_RING - 1)) * CS_COLS;
+		const int s0 = slot(yo) * CS_COLS, sm = slot(yo - 1) * CS_COLS, sp = slot(yo + 1) * CS_COLS;
 		const int c0 = 4 * lane;                       // first frame column of this lane's 8-wide window
 		const int c1 = lane < 63 ? c0 + 4 : c0;        // (lane 63 has no outputs; keep its reads inside the row)
 		cb_u32 mo[4], mu[4], md[4];
@@ -490,7 +487,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 			sum += rb_[j + 1]; sum += rb_[j + 2]; sum += rb_[j + 3];
 			sum += rc_[j + 1]; sum += rc_[j + 2]; sum += rc_[j + 3];
 			const bool inr = (inr_mask >> j) & 1u;
-			res[j] = (inr && !(A.ablate & 2)) ? sum / 9.0f : rb_[j + 2];
+			res[j] = (inr && !(A.ablate & 2)) ? sum / 9.0f : rb_[j + 2];   // adcensus.cu:353-354: copied through
 			if (t != 0) needmask |= 1u << j;
 		}
 		needmask &= inr_mask & valid_mask;
@@ -503,16 +500,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 				const bool nj = (needmask >> j) & 1u;
 				const uint64_t bal = __ballot(nj);
 				const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((cb_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)bal, 0));
-				if (nj) CL[pos] = (unsigned short)(4 * lane + 2 + j);
+				if (nj) CL[pos] = (cb_u32)(4 * lane + 2 + j) | (mo[j] & 0xffff0000u);
 				n += __builtin_popcountll(bal);
 			}
 			*(cb_f2 *)(R + c0 + 2) = cb_f2{res[0], res[1]};
 			if (lane < 63) *(cb_f2 *)(R + c0 + 4) = cb_f2{res[2], res[3]};
+			const int lo_row = max(max(ra, 0), yo + CS_LA - (CS_RING - 1)), hi_row = min(H - 1, yo + CS_LA);
 			for (int e0 = 0; e0 < n; e0 += 64) {
 				const int e = e0 + lane;
 				if (e < n) {
-					const int c = CL[e];
-					R[c] = general(yo, c);
+					const cb_u32 ent = CL[e];
+					const int c = (int)(ent & 0xffffu), u = (int)((ent >> 16) & 0xff), dn = (int)(ent >> 24);
+					// Window form: supports inside rows y-2 .. y+LA of the ring and columns x-2 .. x+2 -- nearly all of
+					// the scattered ones -- are summed from ONE batch of LDS reads: every tap of the window is read,
+					// the taps outside the support add -0.0f (x + -0.0f == x exactly, so the chain of additions is
+					// the reference's), rows ascending and x ascending as in the reference.
+					constexpr int NWR = 3 + CS_LA;
+					cb_u32 mm[NWR];
+					float tv[NWR][5];
+#pragma unroll
+					for (int k = 0; k < NWR; ++k) {
+						const int ro_ = slot(yo + k - 2) * CS_COLS + c;
+						mm[k] = M[ro_];
+#pragma unroll
+						for (int t = 0; t < 5; ++t) tv[k][t] = V[ro_ + t - 2];
+					}
+					bool ok = u <= 2 && dn <= CS_LA && yo - u >= lo_row && yo + dn <= hi_row;
+					float sum = 0;
+					int cnt = 0;
+#pragma unroll
+					for (int k = 0; k < NWR; ++k) {
+						const int rel = k - 2;
+						const bool act = rel >= -u && rel <= dn;
+						const int l = (int)(mm[k] & 0xff), rg = (int)((mm[k] >> 8) & 0xff);
+						ok = ok && (!act || (l <= 2 && rg <= 2));
+						const int la = act ? l : -1, rga = act ? rg : -1;   // inactive row: no tap passes
+						sum += la >= 2 ? tv[k][0] : -0.0f;
+						sum += la >= 1 ? tv[k][1] : -0.0f;
+						sum += act ? tv[k][2] : -0.0f;
+						sum += rga >= 1 ? tv[k][3] : -0.0f;
+						sum += rga >= 2 ? tv[k][4] : -0.0f;
+						cnt += act ? l + rg + 1 : 0;
+					}
+					R[c] = ok ? sum / (float)cnt : general(yo, c, u, dn, lo_row, hi_row);
 				}
 			}
 			const cb_f2 r0 = *(const cb_f2 *)(R + c0 + 2), r1 = *(const cb_f2 *)(R + c1 + (lane < 63 ? 0 : 2));
@@ -605,8 +635,17 @@ int cbca_tiled(const void *packed, const float *vin, float *vout, int D, int H, 
 		A.gx = (int)cdiv(W, CS_STEP); A.gy = (int)cdiv(H, A.nd); A.gz = D;
 		const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(D, 4) * 4;
 		static const int env_pf = [] { const char *e = getenv("MC_CBCA_PF"); return e ? atoi(e) : 0; }();
-		if (env_pf == 2) hipLaunchKernelGGL(cbca_strip_kernel<2>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
-		else hipLaunchKernelGGL(cbca_strip_kernel<4>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+		static const int env_ring = [] { const char *e = getenv("MC_CBCA_RING"); return e ? atoi(e) : 0; }();
+		const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
+		if (env_ring == 5) {
+			hipLaunchKernelGGL((cbca_strip_kernel<2, 5, 2>), grid, block, 0, st, A);
+		} else if (env_ring == 8) {
+			if (env_pf == 4) hipLaunchKernelGGL((cbca_strip_kernel<4, 8, 2>), grid, block, 0, st, A);
+			else hipLaunchKernelGGL((cbca_strip_kernel<2, 8, 2>), grid, block, 0, st, A);
+		} else {
+			if (env_pf == 4) hipLaunchKernelGGL((cbca_strip_kernel<4, 4, 1>), grid, block, 0, st, A);
+			else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1>), grid, block, 0, st, A);
+		}
 		return check_launch("cbca_strip");
 	}
 	// frame width 2 measured best on MI355X for both tight (Middlebury) and looser (KITTI) thresholds; longer arms take
