@@ -37,7 +37,7 @@ size_t cbca_scratch_bytes(int H, int W);
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st);
 int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
                      int direction, hipStream_t st);
-int cbca_tiled(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
+int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
                hipStream_t st);
 size_t fc_workspace_bytes(int C, int n_hidden, int H, int W);
 int fc_stack(const float *featL, const float *featR, int C, int H, int W, int D, const float *const *weights,
@@ -246,7 +246,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		for (int i = 0; i < n_cbca1; ++i) {  // main.lua:998-1001 (ping-pong instead of vol:copy(tmp))
 			for (int v = 0; v < 2; ++v) {
 				float *dst = other(v);
-				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29)) RUN(cbca_tiled(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
+				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096) RUN(cbca_strips(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
 				else RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));  // packed lengths saturate at 255
 				cur[v] = dst;
 			}
@@ -293,7 +293,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		for (int i = 0; i < n_cbca2; ++i) {
 			for (int v = 0; v < 2; ++v) {
 				float *dst = other(v);
-				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29)) RUN(cbca_tiled(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
+				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096) RUN(cbca_strips(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
 				else RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));  // packed lengths saturate at 255
 				cur[v] = dst;
 			}
@@ -504,11 +504,11 @@ int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *v
 	MC_REQUIRE(scratch_bytes >= cbca_scratch_bytes(H, W), "mc_cbca_ws: scratch holds %zu bytes, needs %zu", scratch_bytes,
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws: scratch must be 4-byte aligned");
-	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29), "mc_cbca_ws: image too large for 32-bit plane offsets (use mc_cbca)");
+	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws: image too large for 32-bit plane offsets (use mc_cbca)");
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
-	rc = cbca_tiled(scratch, vol_in, vol_out, D, H, W, direction, -1, st);
+	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st);
 	if (rc) return rc;
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
 }

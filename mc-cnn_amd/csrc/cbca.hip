@@ -85,18 +85,14 @@ int cbca(const float *x0c, const float *x1c, const float *vin, float *vout, int 
 
 
 // =====================================================================================================
-// cbca v2: LDS-staged tiles with packed arm lengths
+// Packed arm lengths
 // =====================================================================================================
 // The reference's support of voxel (d,y,x) is, in the frame of the reference pixel, simply the per-arm MINIMUM of the
 // two images' arm lengths: with len = |end - coordinate| - 1,
 //   yy in [y - min(U0[y,x], U1[y,xp]), y + min(D0[y,x], D1[y,xp])],  xp = x + d*direction,
 //   xx in [x - min(L0[yy,x], L1[yy,xp]), x + min(R0[yy,x], R1[yy,xp])]
 // (adcensus.cu:359-365: max/min of the exclusive ends, the right image's shifted by -d*direction).  Arm lengths are
-// packed as 4 bytes per pixel (L,R,U,D; saturated at 255) by cbca_pack_kernel.  A block owns a TY x TX pixel tile and
-// ND consecutive disparities: it stages the left image's lengths once, derives the halo the tile actually needs from
-// them (min(l0,l1) <= l0, so the bound holds for every d), and per disparity stages the volume tile (+halo) and the
-// byte-wise minimum with the right image's lengths in LDS; every voxel then runs the reference's loop (rows ascending,
-// x ascending, one fp32 accumulator, IEEE divide: bit-identical), out of LDS wherever the support stays inside the frame.
+// packed once per pair as 4 bytes per pixel (L,R,U,D; saturated at 255) by cbca_pack_kernel.
 
 __global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict__ arms, uint32_t *__restrict__ packed, int H, int W,
                                                         uint32_t *__restrict__ overflow)
@@ -125,197 +121,21 @@ __device__ __forceinline__ uint32_t bytemin4(uint32_t a, uint32_t b)
 	return __builtin_bit_cast(uint32_t, me) | (__builtin_bit_cast(uint32_t, mo) << 8);
 }
 
-constexpr int CB_TY = 16;   // output rows per tile
-constexpr int CB_LW = 64;   // staged columns per tile = lanes of a wave
-constexpr int CB_ND = 8;    // disparities per block
-
 struct CbcaArgs {
 	const uint32_t *p0, *p1;      // packed arm lengths (H,W)
 	const float *vin;
 	float *vout;
 	int D, H, W, direction;
-	int nd;                       // disparities per block
+	int rb;                       // output rows per strip
 	const uint32_t *overflow;     // optional: set by cbca_pack when an arm saturated the packed form -> do nothing
-	int ablate;                   // tuning aid (MC_CBCA_ABLATE): 1 = skip aggregation, 2 = skip re-staging
-	int gx, gy, gz;               // tile grid
+	int ablate;                   // tuning aid (MC_CBCA_ABLATE): 1 = skip the larger supports, 2 = copy through
+	int gx, gy;                   // strips per row, row chunks
 };
 
 typedef unsigned cb_u32;
 
-// A block owns 16 rows x (64 - 2*HALO) columns of output and `nd` consecutive disparities.  The staged frame is 64
-// columns wide -- lane i of every wave IS staged column i -- and 16 + 2*HALO rows high, so one wave-load stages one row
-// and LDS offsets are `row * 64 + lane` for both the volume tile and the combined (byte-wise minimum) arm lengths.
-// Staging is register-prefetched two disparities ahead and double-buffered in LDS: global loads of d+1 and d+2 are in
-// flight while d is aggregated.  All global accesses are raw-buffer ops on one (H,W) plane with 32-bit offsets.
-// Supports inside the frame -- nearly all, with the reference's tight colour thresholds -- are summed out of LDS; the
-// minimal 3x3 support takes a straight-line path when a whole wave has it; a row or run that leaves the frame is read
-// from global memory instead (same order of additions), so any arm length is handled in the one launch.
-template <int HALO>
-__global__ void __launch_bounds__(256) cbca_tile_kernel(const CbcaArgs A)
-{
-	constexpr int RY = CB_TY + 2 * HALO;       // staged rows (capacity)
-	constexpr int TXO = CB_LW - 2 * HALO;      // output columns per tile
-	constexpr int NR = (RY + 3) / 4;           // staged rows per wave
-	__shared__ cb_u32 P0t[RY * CB_LW];
-	__shared__ cb_u32 Mt[2][RY * CB_LW];
-	__shared__ float Vt[2][RY * CB_LW];
-
-	if (A.overflow && *A.overflow) return;  // block-uniform: the caller's v1 launch handles this call
-	const int H = A.H, W = A.W, D = A.D, direction = A.direction;
-	const int HWi = H * W;                  // < 2^31 / 4 checked by the launcher
-	const int tid = threadIdx.x;
-	const int lx = tid & 63, wv = tid >> 6;
-	// XCD-aware tile order: blocks b, b+8, b+16, ... run on one XCD (own L2).  Give every XCD one contiguous run of
-	// tiles, walked y-fastest, so that tiles sharing halo rows meet in the same L2 close in time.
-	const int gx = A.gx, gy = A.gy;
-	const int ntiles = gx * gy * A.gz;
-	const int b = blockIdx.x;
-	const int per = (ntiles + 7) >> 3;
-	const int t = (b & 7) * per + (b >> 3);
-	if (t >= ntiles) return;
-	const int bx = t % gx, by = (t / gx) % gy, bz = t / (gy * gx);
-	const int x0 = bx * TXO, y0 = by * CB_TY;
-	const int d0 = bz * A.nd;
-	const int d1 = min(D, d0 + A.nd);
-	const int ty_n = min(CB_TY, H - y0);
-	const int ry0 = max(0, y0 - HALO), ry1 = min(H, y0 + CB_TY + HALO);
-	const int hu = y0 - ry0;
-	const int nrows = ry1 - ry0;
-	const int xs = x0 - HALO + lx;          // image column staged by this lane (may lie outside the image)
-	const bool xs_in = xs >= 0 && xs < W;
-	const bool out_lane = lx >= HALO && lx < HALO + TXO && xs < W;  // this lane produces output (xs >= 0 follows)
-	const int plane_bytes = HWi * 4;
-	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)A.p1, 0, plane_bytes, 0x00020000);
-	const cb_u32 OOB = 0x80000000u;         // voffset beyond num_records: load returns 0, store is dropped
-
-	// the left image's lengths, once per block (each wave reads back only rows it wrote itself)
-	{
-		const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)A.p0, 0, plane_bytes, 0x00020000);
-#pragma unroll
-		for (int i = 0; i < NR; ++i) {
-			const int r = wv + 4 * i;
-			if (r < nrows) P0t[r * CB_LW + lx] = __builtin_amdgcn_raw_buffer_load_b32(rp0, xs_in ? (cb_u32)((ry0 + r) * W + xs) * 4u : OOB, 0, 0);
-		}
-	}
-	// byte offsets (within a plane) of this lane's element in each of its staged rows; OOB where there is none
-	cb_u32 voff[NR];
-#pragma unroll
-	for (int i = 0; i < NR; ++i) {
-		const int r = wv + 4 * i;
-		voff[i] = (r < nrows && xs_in) ? (cb_u32)((ry0 + r) * W + xs) * 4u : OOB;
-	}
-
-	struct Stage { cb_u32 pm[NR]; float pv[NR]; };
-	auto fetch = [&](Stage &st, int d) {   // global -> registers
-		const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
-		const int sh = d * direction;
-		const bool pok = xs_in && xs + sh >= 0 && xs + sh < W;
-#pragma unroll
-		for (int i = 0; i < NR; ++i) {
-			st.pv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, voff[i], 0, 0));
-			st.pm[i] = __builtin_amdgcn_raw_buffer_load_b32(rp1, pok ? voff[i] + (cb_u32)(sh * 4) : OOB, 0, 0);
-		}
-	};
-	auto commit = [&](const Stage &st, int buf) {  // registers -> LDS (lengths combined with the left image's)
-#pragma unroll
-		for (int i = 0; i < NR; ++i) {
-			const int r = wv + 4 * i;
-			if (r < nrows) {
-				Mt[buf][r * CB_LW + lx] = bytemin4(P0t[r * CB_LW + lx], st.pm[i]);
-				Vt[buf][r * CB_LW + lx] = st.pv[i];
-			}
-		}
-	};
-
-	Stage sa, sb;
-	fetch(sa, d0);
-	if (d0 + 1 < d1) fetch(sb, d0 + 1);
-	commit(sa, 0);
-	for (int d = d0; d < d1; ++d) {
-		const int buf = A.ablate == 2 ? 0 : ((d - d0) & 1);
-		// sb holds d+1 (in flight or landed); refill sa with d+2
-		if (d + 2 < d1 && A.ablate != 2) fetch(sa, d + 2);
-		__syncthreads();               // buffer `buf` is complete; buffer `buf^1` is no longer being read
-		const cb_u32 *__restrict__ M = Mt[buf];
-		const float *__restrict__ V = Vt[buf];
-		const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
-		const int sh = d * direction;
-		const bool inr = xs + sh >= 0 && xs + sh < W;
-		if (out_lane) {
-#pragma unroll 1
-			for (int i = 0; i < CB_TY / 4; ++i) {
-				const int r = wv + 4 * i;
-				if (r >= ty_n) break;
-				const int o = (r + hu) * CB_LW + lx;           // LDS index of this pixel (same for M and V)
-				const cb_u32 goff = (cb_u32)((y0 + r) * W + xs) * 4u;
-				if (!inr || A.ablate == 1) {  // adcensus.cu:353-354: copied through
-					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(V[o]), ro, goff, 0, 0);
-					continue;
-				}
-				const cb_u32 mc = M[o];
-				// minimal support (every arm 1 pixel: the 3x3 block) for all output lanes of the wave: straight-line
-				const bool c3 = mc == 0x01010101u;  // implies rows y-1, y+1 and columns x-1, x+1 exist and are staged
-				const cb_u32 ma = M[c3 ? o - CB_LW : o] & 0xffffu, mb = M[c3 ? o + CB_LW : o] & 0xffffu;
-				if (__all(c3 && ma == 0x0101u && mb == 0x0101u)) {
-					const float *vc = V + o;
-					float sum = 0;
-					sum += vc[-CB_LW - 1]; sum += vc[-CB_LW]; sum += vc[-CB_LW + 1];
-					sum += vc[-1]; sum += vc[0]; sum += vc[1];
-					sum += vc[CB_LW - 1]; sum += vc[CB_LW]; sum += vc[CB_LW + 1];
-					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum / 9.0f), ro, goff, 0, 0);
-					continue;
-				}
-				const int u = (int)((mc >> 16) & 0xff), dn = (int)(mc >> 24);
-				const int rr = r + hu;
-				float sum = 0;
-				int cnt = 0;
-				int oq = o - u * CB_LW;                         // LDS index of (row q, this column)
-				for (int q = rr - u; q <= rr + dn; ++q, oq += CB_LW) {
-					const bool row_in = q >= 0 && q < nrows;
-					cb_u32 mm;
-					if (row_in) {
-						mm = M[oq];
-					} else {  // row outside the staged frame: lengths from global memory
-						const int g = (ry0 + q) * W + xs;
-						mm = bytemin4(A.p0[g], A.p1[g + sh]);
-					}
-					const int l = (int)(mm & 0xff), rg = (int)((mm >> 8) & 0xff);
-					const int n = l + rg + 1;
-					if (row_in && lx - l >= 0 && lx + rg < CB_LW) {
-						const float *row = V + oq - l;
-						int k = 0;
-						for (; k + 4 <= n; k += 4) {
-							const float v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3];
-							sum += v0; sum += v1; sum += v2; sum += v3;
-						}
-						if (k < n) {
-							const float v0 = row[k];
-							const float v1 = row[min(k + 1, n - 1)], v2 = row[min(k + 2, n - 1)];
-							sum += v0;
-							if (k + 1 < n) sum += v1;
-							if (k + 2 < n) sum += v2;
-						}
-					} else {  // run leaves the frame: from global memory, same order
-						const float *row = A.vin + (size_t)d * HWi + (ry0 + q) * W + xs - l;
-						for (int k = 0; k < n; ++k) sum += row[k];
-					}
-					cnt += n;
-				}
-				__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum / (float)cnt), ro, goff, 0, 0);
-			}
-		}
-		if (d + 1 < d1 && A.ablate != 2) {
-			commit(sb, buf ^ 1);
-			// rotate the register stages: sb <- sa (d+2)
-#pragma unroll
-			for (int i = 0; i < NR; ++i) { sb.pm[i] = sa.pm[i]; sb.pv[i] = sa.pv[i]; }
-		}
-	}
-}
-
-
 // =====================================================================================================
-// cbca v7: wave-autonomous strips
+// cbca: wave-autonomous strips
 // =====================================================================================================
 // One wave owns one disparity plane, a strip of 256 staged columns (4 per lane, dwordx4 rows of 1 KB) and RB output
 // rows, and walks the strip top to bottom.  Rows are loaded PF steps ahead into registers (volume row, the left image's
@@ -370,7 +190,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 	const int sh = d * direction;
 	const int xs = cx * CS_STEP - 2 + 4 * lane;   // image column of this lane's first staged column
 	const int xo = xs + 2;                        // image column of this lane's first output
-	const int y0 = cy * A.nd, y1 = min(H, y0 + A.nd);   // nd = output rows per strip here
+	const int y0 = cy * A.rb, y1 = min(H, y0 + A.rb);
 	const int ra = y0 - CS_UP;                    // first staged row (rows outside the image: loaded as zeros, never used)
 	const int plane_bytes = HWi * 4;
 	const cb_u32 OOB = 0x80000000u;
@@ -612,58 +432,24 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
 	return check_launch("cbca (overflow path)");
 }
 
-// max_arm: largest arm length that can occur (L1-1 when L1 is known, else < 0); picks the staged frame width.
-// Arm lengths saturate at 255 in the packed form: callers route max_arm > 254 to the v1 kernel.
-int cbca_tiled(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm, hipStream_t st)
+// max_arm: largest arm length that can occur (L1-1 when L1 is known, else < 0: the pack kernel's overflow flag decides).
+// Arm lengths saturate at 255 in the packed form: callers route max_arm > 254 to the direct kernel.
+int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm, hipStream_t st)
 {
-	static const int env_nd = [] { const char *e = getenv("MC_CBCA_ND"); return e ? atoi(e) : 0; }();      // tuning aids
-	static const int env_halo = [] { const char *e = getenv("MC_CBCA_HALO"); return e ? atoi(e) : 0; }();
+	static const int env_abl = [] { const char *e = getenv("MC_CBCA_ABLATE"); return e ? atoi(e) : 0; }();  // tuning aids
+	static const int env_rb = [] { const char *e = getenv("MC_CBCA_RB"); return e ? atoi(e) : 0; }();
 	CbcaArgs A;
 	const CbcaScratch cs = cbca_scratch(packed, H, W);
 	A.p0 = cs.p0; A.p1 = cs.p1;
 	A.vin = vin; A.vout = vout;
 	A.D = D; A.H = H; A.W = W; A.direction = direction;
-	A.nd = CB_ND;
-	(void)env_nd;
-	static const int env_abl = [] { const char *e = getenv("MC_CBCA_ABLATE"); return e ? atoi(e) : 0; }();
 	A.ablate = env_abl;
 	A.overflow = max_arm < 0 ? cs.flag : nullptr;  // unknown arm bound: honour cbca_pack's flag
-	static const int env_kernel = [] { const char *e = getenv("MC_CBCA_KERNEL"); return e ? atoi(e) : 0; }();  // 1 = tile kernel
-	static const int env_rb = [] { const char *e = getenv("MC_CBCA_RB"); return e ? atoi(e) : 0; }();
-	if (env_kernel != 1) {
-		A.nd = env_rb > 0 ? env_rb : 40;  // output rows per strip
-		A.gx = (int)cdiv(W, CS_STEP); A.gy = (int)cdiv(H, A.nd); A.gz = D;
-		const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(D, 4) * 4;
-		static const int env_pf = [] { const char *e = getenv("MC_CBCA_PF"); return e ? atoi(e) : 0; }();
-		static const int env_ring = [] { const char *e = getenv("MC_CBCA_RING"); return e ? atoi(e) : 0; }();
-		const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
-		if (env_ring == 5) {
-			hipLaunchKernelGGL((cbca_strip_kernel<2, 5, 2>), grid, block, 0, st, A);
-		} else if (env_ring == 8) {
-			if (env_pf == 4) hipLaunchKernelGGL((cbca_strip_kernel<4, 8, 2>), grid, block, 0, st, A);
-			else hipLaunchKernelGGL((cbca_strip_kernel<2, 8, 2>), grid, block, 0, st, A);
-		} else {
-			if (env_pf == 4) hipLaunchKernelGGL((cbca_strip_kernel<4, 4, 1>), grid, block, 0, st, A);
-			else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1>), grid, block, 0, st, A);
-		}
-		return check_launch("cbca_strip");
-	}
-	// frame width 2 measured best on MI355X for both tight (Middlebury) and looser (KITTI) thresholds; longer arms take
-	// the per-run global path
-	int halo = (max_arm >= 0 && max_arm < 2) ? 1 : 2;
-	if (env_halo > 0) halo = env_halo;
-	if (halo != 1 && halo != 2 && halo != 3 && halo != 4 && halo != 6) halo = 2;
-	A.gx = (int)cdiv(W, CB_LW - 2 * halo); A.gy = (int)cdiv(H, CB_TY); A.gz = (int)cdiv(D, A.nd);
-	const int64_t ntiles = (int64_t)A.gx * A.gy * A.gz;
-	const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8)), block(256);
-	switch (halo) {
-	case 1: hipLaunchKernelGGL(cbca_tile_kernel<1>, grid, block, 0, st, A); break;
-	case 4: hipLaunchKernelGGL(cbca_tile_kernel<4>, grid, block, 0, st, A); break;
-	case 6: hipLaunchKernelGGL(cbca_tile_kernel<6>, grid, block, 0, st, A); break;
-	case 3: hipLaunchKernelGGL(cbca_tile_kernel<3>, grid, block, 0, st, A); break;
-	default: hipLaunchKernelGGL(cbca_tile_kernel<2>, grid, block, 0, st, A); break;
-	}
-	return check_launch("cbca_tiled");
+	A.rb = env_rb > 0 ? env_rb : 40;
+	A.gx = (int)cdiv(W, CS_STEP); A.gy = (int)cdiv(H, A.rb);
+	const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(D, 4) * 4;
+	hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+	return check_launch("cbca_strip");
 }
 
 }  // namespace mc

@@ -348,7 +348,9 @@ static void launch_pass(const SgmPassArgs &A, bool vec, hipStream_t st)
 	const int waves = A.nvol * nlines * (DUAL ? 2 : 1);
 	const dim3 grid(cdiv(waves, 4)), block(256);
 	// fewer waves than SIMDs (1024): nothing but prefetch depth hides HBM latency
-	const int U = sgm_depth(DIRN, DIRN <= 1 ? 8 : 4);
+	// measured on MI355X (KITTI 370x1226x228): 4 steps ahead for the horizontal and the up sweep, 16 for the down sweep
+	// (three loads per step)
+	const int U = sgm_depth(DIRN, DIRN == 2 ? 16 : 4);
 #define MC_SGM_GO(VPL_, VEC_, U_) \
 	hipLaunchKernelGGL((sgm_pass_kernel<DIRN, VPL_, MODE, ARGMIN, VEC_, U_, DUAL>), grid, block, 0, st, A)
 	if (A.D <= 256) {
