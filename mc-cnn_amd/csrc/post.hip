@@ -139,61 +139,100 @@ int argmin_hwd(const float *vol, float *out, int D, int ds, int H, int W, hipStr
 }
 
 // ---- outlier_detection, adcensus.cu:878-899 ------------------------------------------------
-__global__ void __launch_bounds__(256) outlier_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
-                                                      float *__restrict__ outlier, int64_t size, int W, int disp_max)
+// The reference's inner loop asks, per left pixel x, whether some d in [0, disp_max) has |d - d1[x-d]| < 1.1.  Seen from
+// the right map that is a SCATTER: pixel x' of d1 can only match the few integers d around d1[x'], i.e. the left pixels
+// x = x' + d.  One block per image row marks those pixels in LDS (every candidate d is tested with the reference's own
+// float expression, so the set of marked pixels is exactly the set the loop would find), then classifies the row:
+// O(1) per pixel instead of O(disp_max).
+__global__ void __launch_bounds__(256) outlier_rows_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
+                                                           float *__restrict__ outlier, int W, int disp_max)
 {
-	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (id >= size) return;
-	const int x = (int)(id % W);
-	const int d0i = (int)d0[id];
-	float res;
-	if (x - d0i < 0) {
-		res = 1;
-	} else if ((double)fabsf(d0[id] - d1[id - d0i]) < 1.1) {
-		res = 0;
-	} else {
-		res = 1;
-		for (int d = 0; d < disp_max; ++d) {
-			if (x - d >= 0 && (double)fabsf((float)d - d1[id - d]) < 1.1) {
-				res = 2;
-				break;
+	extern __shared__ unsigned char mark[];
+	const int y = blockIdx.x;
+	const int64_t row = (int64_t)y * W;
+	for (int x = threadIdx.x; x < W; x += 256) mark[x] = 0;
+	__syncthreads();
+	for (int xp = threadIdx.x; xp < W; xp += 256) {
+		const float v = d1[row + xp];
+		// |d - v| < 1.1 with 0 <= d < disp_max needs -1.1 < v < disp_max + 0.1 (NaN fails both tests)
+		if (v > -2.0f && v < (float)disp_max + 2.0f) {
+			const int base = (int)floorf(v);
+#pragma unroll
+			for (int k = -2; k <= 3; ++k) {
+				const int d = base + k;
+				if (d >= 0 && d < disp_max && xp + d < W && (double)fabsf((float)d - v) < 1.1) mark[xp + d] = 1;
 			}
 		}
 	}
-	outlier[id] = res;
+	__syncthreads();
+	for (int x = threadIdx.x; x < W; x += 256) {
+		const int64_t id = row + x;
+		const int d0i = (int)d0[id];
+		float res;
+		if (x - d0i < 0) res = 1;
+		else if ((double)fabsf(d0[id] - d1[id - d0i]) < 1.1) res = 0;
+		else res = mark[x] ? 2.0f : 1.0f;
+		outlier[id] = res;
+	}
 }
 
 int outlier_detection(const float *d0, const float *d1, float *outlier, int H, int W, int disp_max, hipStream_t st)
 {
-	const int64_t size = (int64_t)H * W;
-	hipLaunchKernelGGL(outlier_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, d0, d1, outlier, size, W, disp_max);
+	hipLaunchKernelGGL(outlier_rows_kernel, dim3(H), dim3(256), (size_t)W, st, d0, d1, outlier, W, disp_max);
 	return check_launch("outlier_detection");
 }
 
 // ---- interpolate_occlusion, adcensus.cu:1079-1105 --------------------------------------------
-__global__ void __launch_bounds__(256) interp_occ_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
-                                                         float *__restrict__ out, int64_t size, int W)
+// An occluded pixel takes the disparity of the nearest pixel to its LEFT that passed the left-right check; if the row
+// has none to its left, the reference's second scan finds the first one to the right, which is then the first valid
+// pixel of the row.  Both are row scans: one block per row, each thread owns a short run of pixels, the "last valid
+// index so far" is carried across threads by a max-scan in LDS.
+__global__ void __launch_bounds__(256) interp_occ_rows_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
+                                                              float *__restrict__ out, int W)
 {
-	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (id >= size) return;
-	if (outlier[id] != 1) {
-		out[id] = d0[id];
-		return;
+	__shared__ int carry[256];
+	__shared__ int first_valid;
+	const int y = blockIdx.x, t = threadIdx.x;
+	const int64_t row = (int64_t)y * W;
+	const int seg = (W + 255) / 256;
+	const int xa = t * seg, xb = min(W, xa + seg);
+	if (t == 0) first_valid = W;
+	int last = -1;
+	for (int x = xa; x < xb; ++x)
+		if (outlier[row + x] == 0) last = x;
+	carry[t] = last;
+	__syncthreads();
+	if (last >= 0) {
+		int f = -1;
+		for (int x = xa; x < xb; ++x)
+			if (outlier[row + x] == 0) { f = x; break; }
+		atomicMin(&first_valid, f);
 	}
-	const int x = (int)(id % W);
-	int dx = 0;
-	while (x + dx >= 0 && outlier[id + dx] != 0) dx--;
-	if (x + dx < 0) {
-		dx = 0;
-		while (x + dx < W && outlier[id + dx] != 0) dx++;
+	// inclusive max-scan of carry[] (Hillis-Steele)
+	for (int off = 1; off < 256; off <<= 1) {
+		const int o = t >= off ? carry[t - off] : -1;
+		__syncthreads();
+		carry[t] = max(carry[t], o);
+		__syncthreads();
 	}
-	out[id] = (x + dx < W) ? d0[id + dx] : d0[id];
+	int lv = t > 0 ? carry[t - 1] : -1;   // nearest valid pixel left of this thread's run
+	const int fv = first_valid;
+	for (int x = xa; x < xb; ++x) {
+		const int64_t id = row + x;
+		const float o = outlier[id];
+		if (o == 0) lv = x;
+		float r = d0[id];
+		if (o == 1) {
+			if (lv >= 0) r = d0[row + lv];
+			else if (fv < W) r = d0[row + fv];
+		}
+		out[id] = r;
+	}
 }
 
 int interpolate_occlusion(const float *d0, const float *outlier, float *out, int H, int W, hipStream_t st)
 {
-	const int64_t size = (int64_t)H * W;
-	hipLaunchKernelGGL(interp_occ_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, d0, outlier, out, size, W);
+	hipLaunchKernelGGL(interp_occ_rows_kernel, dim3(H), dim3(256), 0, st, d0, outlier, out, W);
 	return check_launch("interpolate_occlusion");
 }
 
@@ -201,67 +240,66 @@ int interpolate_occlusion(const float *d0, const float *outlier, float *out, int
 // 16 rays; coordinates accumulate in float and are rounded half away from zero (CUDA round()).
 // If every ray leaves the image the reference reads an uninitialised value (assert compiled
 // out); defined here as "keep d0".
-__global__ void __launch_bounds__(256) interp_mis_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
-                                                         float *__restrict__ out, int64_t size, int H, int W)
+// One LANE per ray: the 16 lanes of a DPP row walk the 16 rays of one pixel concurrently (a wave = 4 pixels), then
+// every lane ranks its value against the other 15 with row rotations; the lane whose value has rank n/2 in the
+// ascending order of the n rays that ended inside the image writes it (sort(), adcensus.cu:47-60: equal values are
+// interchangeable, so rank selection returns the same number).
+template <int K> __device__ __forceinline__ void ray_rank_step(float v, int inb, int &less, int &eq)
 {
-	const float dir[32] = {0, 1, -0.5f, 1, -1, 1, -1, 0.5f, -1, 0, -1, -0.5f, -1, -1, -0.5f, -1,
-	                       0, -1, 0.5f, -1, 1, -1, 1, -0.5f, 1, 0, 1, 0.5f, 1, 1, 0.5f, 1};
-	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const float ov = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x120 + K, 0xf, 0xf, false));
+	const int oin = __builtin_amdgcn_update_dpp(0, inb, 0x120 + K, 0xf, 0xf, false);
+	less += (oin && ov < v) ? 1 : 0;
+	eq += (oin && ov == v) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) interp_mis_rays_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
+                                                              float *__restrict__ out, int64_t size, int H, int W)
+{
+	// direction (dx, dy) of ray k, adcensus.cu:1013-1030
+	const float dirx[16] = {0, -0.5f, -1, -1, -1, -1, -1, -0.5f, 0, 0.5f, 1, 1, 1, 1, 1, 0.5f};
+	const float diry[16] = {1, 1, 1, 0.5f, 0, -0.5f, -1, -1, -1, -1, -1, -0.5f, 0, 0.5f, 1, 1};
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t id = t >> 4;
+	const int ray = (int)(threadIdx.x & 15);
 	if (id >= size) return;
-	if (outlier[id] != 2) {
-		out[id] = d0[id];
+	const bool mis = outlier[id] == 2;
+	if (!mis) {
+		if (ray == 0) out[id] = d0[id];
 		return;
 	}
-	float vals[16];
-	int n = 0;
 	const int x = (int)(id % W), y = (int)(id / W);
-#pragma unroll
-	for (int d = 0; d < 16; ++d) {
-		const float dx = dir[2 * d], dy = dir[2 * d + 1];
-		float xx = (float)x, yy = (float)y;
-		int xi = (int)roundf(xx), yi = (int)roundf(yy);
-		while (0 <= yi && yi < H && 0 <= xi && xi < W && outlier[yi * W + xi] == 2) {
-			xx += dx;
-			yy += dy;
-			xi = (int)roundf(xx);
-			yi = (int)roundf(yy);
-		}
-		const bool inb = 0 <= yi && yi < H && 0 <= xi && xi < W;
-		// keep the array fully unrolled (registers): append via select chain
-		const float v = inb ? d0[yi * W + xi] : 0.0f;
-#pragma unroll
-		for (int k = 0; k < 16; ++k)
-			if (k == n && inb) vals[k] = v;
-		n += inb ? 1 : 0;
+	const float dx = dirx[ray], dy = diry[ray];
+	float xx = (float)x, yy = (float)y;
+	int xi = x, yi = y;
+	while (0 <= yi && yi < H && 0 <= xi && xi < W && outlier[yi * W + xi] == 2) {
+		xx += dx;
+		yy += dy;
+		xi = (int)roundf(xx);
+		yi = (int)roundf(yy);
 	}
+	const int inb = (0 <= yi && yi < H && 0 <= xi && xi < W) ? 1 : 0;
+	const float v = inb ? d0[yi * W + xi] : 0.0f;
+	// all 16 lanes of this pixel are here (mis is uniform over the row of 16)
+	int less = 0, eq = inb;
+	ray_rank_step<1>(v, inb, less, eq); ray_rank_step<2>(v, inb, less, eq); ray_rank_step<3>(v, inb, less, eq);
+	ray_rank_step<4>(v, inb, less, eq); ray_rank_step<5>(v, inb, less, eq); ray_rank_step<6>(v, inb, less, eq);
+	ray_rank_step<7>(v, inb, less, eq); ray_rank_step<8>(v, inb, less, eq); ray_rank_step<9>(v, inb, less, eq);
+	ray_rank_step<10>(v, inb, less, eq); ray_rank_step<11>(v, inb, less, eq); ray_rank_step<12>(v, inb, less, eq);
+	ray_rank_step<13>(v, inb, less, eq); ray_rank_step<14>(v, inb, less, eq); ray_rank_step<15>(v, inb, less, eq);
+	const uint64_t bal = __ballot(inb != 0);
+	const int n = __builtin_popcount((unsigned)((bal >> ((threadIdx.x & 48))) & 0xffffu));
 	if (n == 0) {
-		out[id] = d0[id];
+		if (ray == 0) out[id] = d0[id];
 		return;
 	}
-	// median = vals[n/2] of the ascending order (sort(), adcensus.cu:47-60): rank selection, ties are equal values
 	const int want = n / 2;
-	float res = 0;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		if (i < n) {
-			int less = 0, eq = 0;
-#pragma unroll
-			for (int j = 0; j < 16; ++j) {
-				if (j < n) {
-					less += vals[j] < vals[i] ? 1 : 0;
-					eq += vals[j] == vals[i] ? 1 : 0;
-				}
-			}
-			if (less <= want && want < less + eq) res = vals[i];
-		}
-	}
-	out[id] = res;
+	if (inb && less <= want && want < less + eq) out[id] = v;   // lanes that qualify hold the same value
 }
 
 int interpolate_mismatch(const float *d0, const float *outlier, float *out, int H, int W, hipStream_t st)
 {
 	const int64_t size = (int64_t)H * W;
-	hipLaunchKernelGGL(interp_mis_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, d0, outlier, out, size, H, W);
+	hipLaunchKernelGGL(interp_mis_rays_kernel, dim3(cdiv(size * 16, 256)), dim3(256), 0, st, d0, outlier, out, size, H, W);
 	return check_launch("interpolate_mismatch");
 }
 
