@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box via gpurun): bash scripts/gpu_full.sh <tag>
 # Everything the round's evidence needs: -m gpu tests, smoke, bench lines (3 configs, with CPU baseline and the
-# reference-on-GPU leg), rocprofv3 kernel stats, PMC traffic passes.
+# reference-on-GPU leg; plus the accurate net end to end from features), rocprofv3 kernel stats, PMC traffic passes.
 TAG=${1:-full}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
 nproc > $O/nproc.txt
@@ -10,6 +10,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 timeout 400 python bench.py --steps 30 --warmup 3 > $O/bench_kitti_fast.json 2> $O/bench_kitti_fast.err
 timeout 400 python bench.py --config kitti_slow --steps 20 --warmup 3 > $O/bench_kitti_slow.json 2> $O/bench_kitti_slow.err
 timeout 400 python bench.py --config mb_slow --steps 5 --warmup 1 > $O/bench_mb_slow.json 2> $O/bench_mb_slow.err
+timeout 400 python bench.py --config kitti_slow_fc --steps 3 --warmup 1 > $O/bench_kitti_slow_fc.json 2> $O/bench_kitti_slow_fc.err
 for c in kitti_fast kitti_slow mb_slow; do python -c "
 import json; j=json.load(open('$O/bench_$c.json')); print('$c', j['value'], j['ms_per_step'], j['stage_ms'], j['roofline']['frac'], (j.get('reference_on_gpu') or {}).get('ms_per_pair'), j['cpu_baseline']['value'] if j.get('cpu_baseline') else None)"; done
 bash scripts/gpu_prof.sh $TAG kitti_fast 10 > /dev/null
