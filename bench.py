@@ -249,7 +249,7 @@ def main():
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(dom)
         roof = dict(bound="hbm", kernel={"sgm": "sgm_pass_kernel (right+left sweep, down sweep, up sweep: 3 launches over both volumes)",
-                                         "cbca": "cbca_tile_kernel (one launch per iteration per volume)"}[dom],
+                                         "cbca": "cbca_strip_kernel (one launch per iteration per volume)"}[dom],
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=traffic, launches_per_step=n_launch,
                     algorithmic_bytes_per_launch=round(ab[dom] / n_launch),

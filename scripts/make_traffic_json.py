@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """profiles/traffic_<config>.json from the PMC passes of scripts/gpu_pmc.sh: measured HBM-side bytes per LAUNCH of the
-dominant kernel groups (`sgm`: the sgm_pass_kernel launches of one step; `cbca`: cbca_tile_kernel), collected and
+dominant kernel groups (`sgm`: the sgm_pass_kernel launches of one step; `cbca`: cbca_strip_kernel), collected and
 corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes, FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE x2 on
 gfx950 (128-byte requests tallied as 64 B), WRITE_SIZE at face value.
   python scripts/make_traffic_json.py gpurun_out/<tag>/pmc_<config> <config>"""
@@ -19,7 +19,7 @@ def main(d, config):
             if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean over dispatches; source: " + d}
-    groups = {"sgm": "sgm_pass_kernel", "cbca": "cbca_tile_kernel", "join": "join_mfma_kernel", "transpose": "transpose_kernel"}
+    groups = {"sgm": "sgm_pass_kernel", "cbca": "cbca_strip_kernel", "join": "join_mfma_kernel", "transpose": "transpose_kernel"}
     for g, pat in groups.items():
         ks = [k for k in acc if pat in k]
         if not ks:
