@@ -92,18 +92,20 @@ def test_cbca(mc, oracle, H, W, D, L1, tau1, direction):
     want = oracle.cbca(x0c, x1c, vol, direction)
     out = torch.empty((1, D, H, W), device="cuda")
     mc.adcensus.cbca(dev(x0c), dev(x1c), dev(vol), out, direction)
-    assert_same(host(out), want, "cbca (LDS-tiled, mc_cbca_ws)")
+    assert_same(host(out), want, "cbca (packed-arm strips, mc_cbca_ws)")
     out2 = torch.empty((1, D, H, W), device="cuda")
     mc.adcensus.cbca_reference_shaped(dev(x0c), dev(x1c), dev(vol), out2, direction)
     assert_same(host(out2), want, "cbca (mc_cbca)")
 
 
-@pytest.mark.parametrize("H,W,D", [(50, 200, 40), (33, 131, 17), (16, 64, 8), (17, 65, 9), (70, 90, 100)])
+@pytest.mark.parametrize("H,W,D", [(50, 200, 40), (33, 131, 17), (16, 64, 8), (17, 65, 9), (70, 90, 100),
+                                   (20, 253, 6), (45, 519, 5), (9, 1010, 3), (83, 254, 3), (3, 5, 2)])
 @pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.02), ("smooth", 14, 0.3), ("blocky", 14, 0.2), ("flat", 13, 1.0),
                                         ("flat", 30, 1.0), ("blocky", 40, 0.3), ("random", 5, 0.13)])
 @pytest.mark.parametrize("direction", [-1, 1])
-def test_cbca_tiled_shapes(mc, oracle, H, W, D, mk, L1, tau1, direction):
-    """Tile edges (H % 16, W % 64), halos from 1 to the staged capacity, and arms beyond it (in-launch fallback)."""
+def test_cbca_strip_shapes(mc, oracle, H, W, D, mk, L1, tau1, direction):
+    """Strip edges (W around multiples of 252, W % 4 != 0), row chunks (H % 40), D % 4 != 0, supports from the minimal 3x3
+    through the window form to arms far beyond the LDS ring (in-launch global fallback)."""
     if mk == "smooth":
         x0, x1 = smooth_pair(H, W, min(D, 8), seed=H)
     elif mk == "blocky":
@@ -120,7 +122,7 @@ def test_cbca_tiled_shapes(mc, oracle, H, W, D, mk, L1, tau1, direction):
     want = oracle.cbca(x0c, x1c, vol, direction)
     out = torch.empty((1, D, H, W), device="cuda")
     mc.adcensus.cbca(dev(x0c), dev(x1c), dev(vol), out, direction)
-    assert_same(host(out), want, "cbca tiled")
+    assert_same(host(out), want, "cbca strips")
 
 
 SGM_PARAMS = [  # pi1, pi2, tau_so, alpha1, q1, q2
