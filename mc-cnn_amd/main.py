@@ -75,8 +75,15 @@ FC_SHAPES = {"kitti": (4, 384), "kitti2015": (4, 384), "mb": (3, 384)}  # (l2, n
 
 
 def load_net(net_fname, dataset, arch, n_input_plane=1):
-    """[(w, b)] of the feature net: from an .npz, or seeded random (`random:<seed>`)."""
+    """[(w, b)] of the feature net: from the reference's `.t7` (torch.save(..., 'ascii'), main.lua:587-600), an .npz, or
+    seeded random (`random:<seed>`)."""
     l1, fm = NET_SHAPES[(dataset, arch)]
+    if net_fname.endswith(".t7"):
+        from . import t7
+        layers = t7.load_reference_net(net_fname, arch)[0]
+        if not layers:
+            raise ValueError("%s: no SpatialConvolution modules found" % net_fname)
+        return layers
     if net_fname.startswith("random:"):
         rng = np.random.default_rng(int(net_fname.split(":")[1]))
         layers = []
@@ -91,8 +98,15 @@ def load_net(net_fname, dataset, arch, n_input_plane=1):
 
 
 def load_fc(net_fname, dataset):
-    """[(w (out,in), b (out))] of net_te2 (arch slow, main.lua:688-695): from an .npz (fw1,fb1,...) or seeded random."""
+    """[(w (out,in), b (out))] of net_te2 (arch slow, main.lua:688-695): from the reference's `.t7`, an .npz (fw1,fb1,...)
+    or seeded random."""
     l1, fm = NET_SHAPES[(dataset, "slow")]
+    if net_fname.endswith(".t7"):
+        from . import t7
+        fc = t7.load_reference_net(net_fname, "slow")[1]
+        if not fc:
+            raise ValueError("%s: no SpatialConvolution1_fw modules found" % net_fname)
+        return fc
     l2, nh2 = FC_SHAPES[dataset]
     dims = [2 * fm] + [nh2] * l2 + [1]
     if net_fname.startswith("random:"):

@@ -41,3 +41,212 @@ def test_rgb2y_and_random_net_are_deterministic():
     b = mcmain.load_net("random:5", "kitti", "fast")
     assert len(a) == 4 and a[0][0].shape == (64, 1, 3, 3) and a[1][0].shape == (64, 64, 3, 3)
     assert all(np.array_equal(x[0], y[0]) for x, y in zip(a, b))
+
+
+# ---- on-disk formats ---------------------------------------------------------------------------------------
+# A net file as torch.save(fname, {net_te, opt}, 'ascii') lays it out (torch7 File.lua / generic/Tensor.c), written by
+# hand: a table {1: nn.Sequential{modules = {1: cudnn.SpatialConvolution{weight 2x1x1x2 (a view into a 6-element storage
+# at offset 2), bias, nOutputPlane, kH, kW}, 2: cudnn.ReLU{inplace}}}, 2: {fm = 2, name = "kitti"}}.
+T7_ASCII_SAMPLE = b"""3
+1
+2
+1
+1
+4
+2
+3
+V 1
+13
+nn.Sequential
+3
+3
+1
+2
+7
+modules
+3
+4
+2
+1
+1
+4
+5
+3
+V 1
+24
+cudnn.SpatialConvolution
+3
+6
+5
+2
+6
+weight
+4
+7
+3
+V 1
+16
+torch.CudaTensor
+4
+2 1 1 2
+2 2 2 1
+2
+4
+8
+3
+V 1
+17
+torch.CudaStorage
+6
+9 0.5 -1.25 3 4e-1 7
+2
+4
+bias
+4
+9
+3
+V 1
+16
+torch.CudaTensor
+1
+2
+1
+1
+4
+10
+3
+V 1
+17
+torch.CudaStorage
+2
+0.125 -8
+2
+12
+nOutputPlane
+1
+2
+2
+2
+kH
+1
+1
+2
+2
+kW
+1
+2
+1
+2
+4
+11
+3
+V 1
+10
+cudnn.ReLU
+3
+12
+1
+2
+7
+inplace
+5
+1
+1
+2
+3
+13
+2
+2
+2
+fm
+1
+2
+2
+4
+name
+2
+5
+kitti
+"""
+
+
+def test_t7_reader_on_a_hand_written_ascii_net():
+    from mc_cnn_amd import t7
+    obj = t7.load(T7_ASCII_SAMPLE)
+    assert sorted(obj) == [1, 2] and obj[2] == {"fm": 2, "name": "kitti"}
+    seq = obj[1]
+    assert seq.cls == "nn.Sequential" and seq["modules"][2].cls == "cudnn.ReLU" and seq["modules"][2]["inplace"] is True
+    (w, b), = t7.conv_layers(seq)
+    assert w.shape == (2, 1, 1, 2) and w.dtype == np.float32
+    np.testing.assert_array_equal(w.reshape(2, 2), np.array([[0.5, -1.25], [3.0, 0.4]], np.float32))  # offset 2, strides 2,2,2,1
+    np.testing.assert_array_equal(b, np.array([0.125, -8.0], np.float32))
+
+
+def test_t7_round_trip_of_a_slow_net_and_main_loaders(tmp_path):
+    from mc_cnn_amd import t7
+    rng = np.random.default_rng(5)
+    convs = [(rng.standard_normal((4, 1 if i == 0 else 4, 3, 3)).astype(np.float32), rng.standard_normal(4).astype(np.float32))
+             for i in range(2)]
+    fcs = [(rng.standard_normal((6, 8)).astype(np.float32), rng.standard_normal(6).astype(np.float32)),
+           (rng.standard_normal((1, 6)).astype(np.float32), rng.standard_normal(1).astype(np.float32))]
+
+    def seq(mods):
+        return t7.T7Object("nn.Sequential", {"modules": mods, "train": False})
+
+    relu = lambda: t7.T7Object("cudnn.ReLU", {"inplace": True})
+    net_te = seq([m for w, b in convs for m in (t7.T7Object("cudnn.SpatialConvolution", {
+        "weight": w, "bias": b, "nInputPlane": w.shape[1], "nOutputPlane": w.shape[0], "kH": 3, "kW": 3, "padH": 1, "padW": 1}), relu())])
+    shared = relu()  # the same object twice: written once, referenced by index the second time
+    net_te2 = seq([t7.T7Object("nn.SpatialConvolution1_fw", {"weight": fcs[0][0], "bias": fcs[0][1].reshape(1, -1, 1, 1)}), shared,
+                   t7.T7Object("nn.SpatialConvolution1_fw", {"weight": fcs[1][0], "bias": fcs[1][1].reshape(1, -1, 1, 1)}), shared,
+                   t7.T7Object("cudnn.Sigmoid", {"inplace": True})])
+    path = str(tmp_path / "net_kitti_slow.t7")
+    t7.save(path, [net_te, net_te2, {"a": "train_tr", "l1": 2, "fm": 4, "at": 0.5, "debug": False}])
+    obj = t7.load(path)
+    assert obj[3] == {"a": "train_tr", "l1": 2, "fm": 4, "at": 0.5, "debug": False}
+    assert obj[2]["modules"][2] is obj[2]["modules"][4]
+    got_c, got_f = t7.load_reference_net(path, "slow")
+    for (w, b), (w2, b2) in zip(convs + fcs, got_c + got_f):
+        np.testing.assert_array_equal(w, w2)
+        np.testing.assert_array_equal(b, b2)
+    # main.py picks the .t7 up by extension
+    lc = mcmain.load_net(path, "kitti", "slow")
+    lf = mcmain.load_fc(path, "kitti")
+    np.testing.assert_array_equal(lc[1][0], convs[1][0])
+    np.testing.assert_array_equal(lf[0][0], fcs[0][0])
+    # binary mode carries the same objects
+    import struct
+    blob = struct.pack("<i", 1) + struct.pack("<d", 2.5)
+    assert t7.load(blob, mode="binary") == 2.5
+
+
+def test_dataset_bin_with_sidecars_round_trip(tmp_path):
+    from mc_cnn_amd import binio
+    x = (np.arange(2 * 3 * 4, dtype=np.float32) * 0.5).reshape(2, 3, 4)
+    nnz = np.array([[1, 2, 3, 4], [5, 6, 7, 8]], np.int32)
+    binio.tofile(str(tmp_path / "x0.bin"), x)
+    binio.tofile(str(tmp_path / "nnz.bin"), nnz)
+    assert (tmp_path / "x0.bin.dim").read_text().split() == ["2", "3", "4"] and (tmp_path / "x0.bin.type").read_text() == "float32"
+    np.testing.assert_array_equal(binio.fromfile(str(tmp_path / "x0.bin")), x)
+    got = binio.fromfile(str(tmp_path / "nnz.bin"))
+    assert got.dtype == np.int32
+    np.testing.assert_array_equal(got, nnz)
+    (tmp_path / "empty.bin").write_bytes(b"")
+    (tmp_path / "empty.bin.dim").write_text("0\n")
+    (tmp_path / "empty.bin.type").write_text("float32")
+    assert binio.fromfile(str(tmp_path / "empty.bin")).size == 0
+
+
+def test_png16_and_pfm_follow_adcensus(tmp_path):
+    from mc_cnn_amd import binio
+    d = np.array([[0.0, 1e-6, 1.0, 12.5], [3.00390625, 255.99, 100.0, 0.5]], np.float32)
+    p = str(tmp_path / "d.png")
+    binio.write_png16(d, p)
+    back = binio.read_png16(p)
+    want = np.array([[0, 0, 256, 3200], [769, 65533, 25600, 128]], np.float32) / 256.0
+    np.testing.assert_array_equal(back, want.astype(np.float32))
+    q = str(tmp_path / "d.pfm")
+    binio.write_pfm(d, q)
+    raw = open(q, "rb").read()
+    head = b"Pf\n4 2\n-0.003922\n"
+    assert raw.startswith(head) and np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(2, 4), d)
