@@ -9,8 +9,11 @@ convolutions go through PyTorch-ROCm / MIOpen, everything after them through lib
 pipeline in one `mc_predict` call, and writes `left.bin`, `right.bin` (1,D,H,W) and `disp.bin` (1,1,H,W), raw float32,
 with the reference's messages.  `-a time` is main.lua:1140-1167 (min of N runs on an uninitialised batch).
 
--net_fname: the reference loads a Torch7 `.t7` file (main.lua:892-902), which this image cannot read (no Torch7); here
-it is an `.npz` with arrays w1,b1,...,w<l1>,b<l1> (w_i: (fm, in, 3, 3)), or `random:<seed>` for a seeded random net
+Architectures: fast, slow (feature net + `mc_fc_stack`, main.lua:958-983), ad and census (no net: `mc_ad` / `mc_census_ws`
+volumes from the image pair, main.lua:932-942).
+
+-net_fname: the reference's Torch7 `net_*.t7` (main.lua:892-902; read by `t7.py`), an `.npz` with arrays
+w1,b1,...,w<l1>,b<l1> (w_i: (fm, in, 3, 3); arch slow also fw1,fb1,...), or `random:<seed>` for a seeded random net
 (there is no network access for trained weights).  Hyper-parameter flags (-L1 -tau1 -cbca_i1 -cbca_i2 -pi1 -pi2 -sgm_i
 -sgm_q1 -sgm_q2 -alpha1 -tau_so -blur_sigma -blur_t) default to main.lua's per-(dataset, arch) tables.
 """
@@ -164,16 +167,27 @@ def main(argv=None):
     dataset, arch, opt, prm = parse(list(sys.argv[1:] if argv is None else argv))
     import torch
     from .predict import Workspace, stereo_predict_fused
-    if arch not in ("fast", "slow"):
-        raise SystemExit("main.py: -a %s is wired for arch fast and slow; arch %s goes through the library entry points "
-                         "(adcensus.ad / adcensus.census + stereo_predict_fused(raw=...))" % (opt.a, arch))
+    if arch not in ("fast", "slow", "ad", "census"):
+        raise SystemExit("main.py: unknown architecture %r (main.lua:11: fast | slow | ad | census)" % arch)
     dev = torch.device("cuda", opt.gpu - 1)
     torch.cuda.set_device(dev)
-    layers = load_net(opt.net_fname, dataset, arch)
+    learned = arch in ("fast", "slow")
+    layers = load_net(opt.net_fname, dataset, arch) if learned else []
     fc_layers = load_fc(opt.net_fname, dataset) if arch == "slow" else None
     prm["border_n"] = len(layers)  # (1 + l1*(3-1) - 1) / 2, main.lua:382-391,923
 
     def run(x_batch, D, workspace=None, want_volumes=False):
+        if not learned:  # main.lua:932-942: hand-crafted costs straight from the image pair, no border fix
+            from . import adcensus
+            cost = adcensus.ad if arch == "ad" else adcensus.census
+            H, W = x_batch.shape[2:]
+            volL = torch.empty((1, D, H, W), dtype=torch.float32, device=x_batch.device)
+            volR = torch.empty_like(volL)
+            adcensus.fill_nan(volL)
+            adcensus.fill_nan(volR)
+            cost(x_batch[0:1], x_batch[1:2], volL, -1)
+            cost(x_batch[1:2], x_batch[0:1], volR, 1)
+            return stereo_predict_fused(x_batch, prm, D, raw=(volL, volR), workspace=workspace, want_volumes=want_volumes)
         if arch == "fast":
             return stereo_predict_fused(x_batch, prm, D, feat=features_fast(x_batch, layers), workspace=workspace,
                                         want_volumes=want_volumes)

@@ -373,6 +373,31 @@ def test_main_predict_writes_the_reference_files(mc, oracle, tmp_path, monkeypat
     assert_same(disp, want["disp"], "disp.bin")
 
 
+@pytest.mark.parametrize("arch", ["ad", "census"])
+def test_main_predict_hand_crafted_costs(mc, oracle, tmp_path, monkeypatch, arch):
+    """`main.py kitti ad|census -a predict` (main.lua:932-942): cost volumes straight from the image pair."""
+    from PIL import Image
+    from mc_cnn_amd import main as mcmain
+    H, W, D = 33, 70, 12
+    rng = np.random.default_rng(9)
+    from scipy.ndimage import gaussian_filter
+    base = gaussian_filter(rng.random((H, W + 5)), 1.5)
+    base = ((base - base.min()) / np.ptp(base) * 255).astype(np.uint8)
+    Image.fromarray(base[:, 5:]).save(tmp_path / "L.png")
+    Image.fromarray(base[:, :W]).save(tmp_path / "R.png")
+    monkeypatch.chdir(tmp_path)
+    assert mcmain.main(["kitti", arch, "-a", "predict", "-left", "L.png", "-right", "R.png", "-disp_max", str(D)]) == 0
+    x0 = mcmain.normalize(mcmain.load_image("L.png"))
+    x1 = mcmain.normalize(mcmain.load_image("R.png"))
+    prm = dict(mc.TABLES[("kitti", arch)])
+    cost = oracle.ad if arch == "ad" else oracle.census
+    rawL, rawR = cost(x0, x1, D, -1), cost(x1, x0, D, 1)
+    want = oracle.stereo_predict(prm, x0[0], x1[0], D, rawL=rawL, rawR=rawR)
+    assert_same(mc.read_bin("left.bin", (1, D, H, W)), want["volL"], "left.bin")
+    assert_same(mc.read_bin("right.bin", (1, D, H, W)), want["volR"], "right.bin")
+    assert_same(mc.read_bin("disp.bin", (1, 1, H, W)), want["disp"], "disp.bin")
+
+
 def test_errors_are_loud(mc):
     """Bad arguments raise (reference: Lua error), they never fall back."""
     t = torch.zeros((1, 4, 8, 8), device="cuda")
