@@ -50,6 +50,7 @@ int stereo_join_dhw(const float *fL, const float *fR, float *volL, float *volR, 
 // outside the image (the reference's fill(0/0), main.lua:946): "virtual" tiles p0 >= W exist only to write
 // the right volume's NaN triangle.  fix_border is a separate small copy.
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned cb_u4_t __attribute__((ext_vector_type(4)));
 
 template <int KSTEPS>  // KSTEPS = ceil(C/2) rounded up to a supported size
 __global__ void __launch_bounds__(256) join_mfma_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
@@ -173,6 +174,172 @@ __global__ void __launch_bounds__(256) join_mfma_kernel(const float *__restrict_
 	}
 }
 
+// ---- (H,W,ds) outputs, line-aligned stores: every tile computed by the owner of each volume ---------------------
+// PMC on join_mfma_kernel: 1.14 GB written and 0.42 GB read for 0.83 GB + 0.12 GB algorithmic -- its 128-byte store
+// pieces start wherever d = m - n + 32J falls inside a pixel's 912-byte run, leave L2 as partial 32-byte sectors and
+// come back as read-modify-writes.  Here a wave OWNS 32 pixels of ONE volume and walks all partner tiles J itself
+// (SIDE 0: left pixels, partners x - d; SIDE 1: right pixels, partners x + d -- the MFMAs are issued twice per pair of
+// volumes, 2 x 13 GFLOP is still < 0.25 ms of fp32 MFMA), so the 32 disparities a tile adds to each of its pixels
+// extend that pixel's run contiguously.  They are parked in a 64-float LDS ring per pixel; after every tile the
+// 128-byte LINES of the volume that have become complete are written, 8 lanes x 16 bytes per line -- full, aligned
+// lines only, apart from the first and last line of a pixel's run.
+template <int KSTEPS, int SIDE>
+__device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, const float *__restrict__ fR, float *__restrict__ vol,
+                                                 int C, int D, int ds, int H, int W, int y, int tile0, float *__restrict__ rings, int ablate)
+{
+	// A wave owns TWO adjacent tiles (64 pixels) of one volume: both multiply against the same partner tile in the same
+	// step (with disparity offsets one tile apart), so every partner tile is fetched once per two tile products.
+	constexpr int NT = 2;
+	const int lane = threadIdx.x & 63;
+	const int nl = lane & 31, kh = lane >> 5;
+	const int64_t HW = (int64_t)H * W;
+	const unsigned feat_bytes = (unsigned)(((int64_t)(C - 1) * HW + W) * 4);
+	const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)(fL + (int64_t)y * W), 0, feat_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)(fR + (int64_t)y * W), 0, feat_bytes, 0x00020000);
+	const unsigned pair_bytes = (unsigned)(2 * HW * 4);
+	const unsigned OOBF = 0x80000000u;
+	const float NANV = __builtin_nanf("");
+	// operand of the tile starting at pixel p0 (lane part: pixel nl of the tile, channel parity kh); outside the image: 0
+	auto load_tile = [&](float (&v)[KSTEPS], const __amdgpu_buffer_rsrc_t &r, int p0, bool negate) {
+		const int px = p0 + nl;
+		const unsigned vo = (px >= 0 && px < W) ? (unsigned)((int64_t)kh * HW + px) * 4u : OOBF;
+#pragma unroll
+		for (int kk = 0; kk < KSTEPS; ++kk) {
+			const int c = 2 * kk + kh;
+			const float t = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, c < C ? vo : OOBF, kk * pair_bytes, 0));
+			v[kk] = negate ? -t : t;
+		}
+	};
+	// (the minus sign of -L*R always goes to the OWN operand, loaded once: (-L)*R and L*(-R) are the same bits, and a
+	// prefetched partner value that needs no arithmetic needs no wait until its MFMA)
+	auto load_partner = [&](float (&v)[KSTEPS], int T) { load_tile(v, SIDE == 0 ? rB : rA, 32 * T, false); };
+	float own[NT][KSTEPS], pa[KSTEPS], pb[KSTEPS];
+#pragma unroll
+	for (int t = 0; t < NT; ++t) load_tile(own[t], SIDE == 0 ? rA : rB, 32 * (tile0 + t), true);
+	const int nJ = (D + 30) / 32 + 1;
+	// partner tile of step s: SIDE 0 walks left from tile0+1, SIDE 1 right from tile0; own tile t sees it as its
+	// J = (SIDE 0: tile0 + t - T, SIDE 1: T - tile0 - t), active while 0 <= J < nJ
+	const int nsteps = nJ + NT - 1;
+	auto partner_of = [&](int s) { return SIDE == 0 ? tile0 + NT - 1 - s : tile0 + s; };
+	load_partner(pa, partner_of(0));
+
+	// C/D layout of a tile: col n = lane & 31 (right pixel), row m = mc_i + 4 * (lane >> 5), mc_i = (i & 3) + 8 * (i >> 2)
+	// (left pixel); d = m - n + 32J in both roles.  Ring slot of element i: (d & 63) in the row of its owner pixel
+	// (SIDE 0: m, SIDE 1: n); J only toggles bit 5 of the slot.
+	const int wbase = 4 * kh - nl;                       // d = wbase + mc_i + 32J
+	const int wrow = SIDE == 0 ? 4 * kh * 64 : nl * 64;  // (+ mc_i * 64 for SIDE 0)
+
+	// line writer: lane -> (pixel fo = 8*pass + lane/8, 16-byte piece fp = lane%8).  Pixel o holds every d <= 32J + c_o
+	// after tile J (c_o = o for SIDE 0, 31 - o for SIDE 1); line k of pixel o covers d in [32k - a_o, 32k - a_o + 31],
+	// a_o = offset of the pixel's run inside a 128-byte line.  Exactly one line per pixel completes per tile:
+	// k = kl_o + J with kl_o = floor((c_o + a_o - 63) / 32) + 1; the last tile also completes the line after it.
+	const int fp = lane & 7;
+	const int row_floats = W * ds;
+	const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(vol + (int64_t)y * row_floats), 0, row_floats * 4, 0x00020000);
+	const int row_mis = (int)(((int64_t)y * row_floats) & 31);
+	int fd0[NT][4];          // first disparity of this lane's piece of the line that completes at J = 0 (may be negative)
+	unsigned fgo[NT][4];     // byte offset of the pixel's run in the image row, or out of range if the pixel is outside the image
+#pragma unroll
+	for (int t = 0; t < NT; ++t) {
+#pragma unroll
+		for (int pass = 0; pass < 4; ++pass) {
+			const int px = 32 * (tile0 + t) + pass * 8 + (lane >> 3);
+			const int fo = pass * 8 + (lane >> 3);
+			const int a_o = (row_mis + px * ds) & 31;
+			const int c_o = SIDE == 0 ? fo : 31 - fo;
+			const int kl = ((c_o + a_o - 63 + 64) >> 5) - 2 + 1;
+			fd0[t][pass] = 32 * kl - a_o + 4 * fp;
+			fgo[t][pass] = px < W ? (unsigned)(px * ds) * 4u : OOBF;
+		}
+	}
+	auto do_tile = [&](int t, int J, const float (&part)[KSTEPS], int p0) {
+		float *__restrict__ ring = rings + t * (32 * 64);
+		floatx16 acc;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+		// partner tile entirely outside the image: nothing to multiply, the whole tile is NaN
+		const bool any_in = SIDE == 0 ? (p0 + 31 >= 0) : (p0 < W);
+		if (any_in && !(ablate & 4)) {
+#pragma unroll
+			for (int kk = 0; kk < KSTEPS; ++kk)
+				acc = SIDE == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(own[t][kk], part[kk], acc, 0, 0, 0)
+				                : __builtin_amdgcn_mfma_f32_32x32x2f32(part[kk], own[t][kk], acc, 0, 0, 0);
+		}
+		const int jbit = (J & 1) << 5;
+		// interior tile: every d of it lies in [0, D) and every partner pixel inside the image
+		const bool interior = J >= 1 && 32 * J + 31 < D && (SIDE == 0 ? p0 >= 0 : p0 + 31 < W);
+		if (ablate & 2) {
+			if (acc[0] == 12345.0f) ring[wrow] = acc[3] + part[0];
+		} else if (interior) {
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int mc = (i & 3) + 8 * (i >> 2);
+				ring[wrow + (SIDE == 0 ? mc * 64 : 0) + (((wbase + mc) & 63) ^ jbit)] = acc[i];
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int mc = (i & 3) + 8 * (i >> 2);
+				const int d = wbase + mc + 32 * J;
+				const int po = SIDE == 0 ? p0 + nl : p0 + mc + 4 * kh;   // partner pixel of this element
+				const bool pin = SIDE == 0 ? po >= 0 : po < W;           // (the other bound cannot be violated for d >= 0)
+				if (d >= 0 && d < D) ring[wrow + (SIDE == 0 ? mc * 64 : 0) + (((wbase + mc) & 63) ^ jbit)] = pin ? acc[i] : NANV;
+			}
+		}
+		if (ablate & 1) return;
+		const bool last = J + 1 == nJ;
+#pragma unroll
+		for (int pass = 0; pass < 4; ++pass) {
+			const int d0 = fd0[t][pass] + 32 * J;
+			const int fro = (pass * 8 + (lane >> 3)) * 64;
+			// (unsigned)d0 < ds  <=>  the piece holds at least one d of [0, D) of THIS pixel (d0 % 4 == 0, ds = D rounded up to 4)
+			const float4 v = *(const float4 *)(ring + fro + (d0 & 63));
+			__builtin_amdgcn_raw_buffer_store_b128((cb_u4_t){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
+			                                       rrow, (unsigned)d0 < (unsigned)ds ? fgo[t][pass] + (unsigned)d0 * 4u : OOBF, 0, 0);
+			if (last) {
+				const int d1 = d0 + 32;
+				const float4 u = *(const float4 *)(ring + fro + (d1 & 63));
+				__builtin_amdgcn_raw_buffer_store_b128((cb_u4_t){__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(u.z), __float_as_uint(u.w)},
+				                                       rrow, (unsigned)d1 < (unsigned)ds ? fgo[t][pass] + (unsigned)d1 * 4u : OOBF, 0, 0);
+			}
+		}
+	};
+	auto do_step = [&](int s, const float (&part)[KSTEPS]) {
+		const int T = partner_of(s);
+#pragma unroll
+		for (int t = 0; t < NT; ++t) {
+			const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
+			if (J >= 0 && J < nJ) do_tile(t, J, part, 32 * T);
+		}
+	};
+	for (int s = 0; s < nsteps; s += 2) {
+		if (s + 1 < nsteps) load_partner(pb, partner_of(s + 1));
+		do_step(s, pa);
+		if (s + 1 < nsteps) {
+			if (s + 2 < nsteps) load_partner(pa, partner_of(s + 2));
+			do_step(s + 1, pb);
+		}
+	}
+}
+
+template <int KSTEPS>
+__global__ void __launch_bounds__(256) join_owner_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
+                                                         float *__restrict__ volL, float *__restrict__ volR, int C, int D, int ds,
+                                                         int H, int W, int pairs_per_row, int ablate)
+{
+	__shared__ __attribute__((aligned(16))) float rings[4][2 * 32 * 64];
+	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	// XCD-aware mapping as in join_mfma_kernel: all blocks of one image row on one XCD
+	const int b = blockIdx.x;
+	const int xcd = b & 7, k = b >> 3;
+	const int blocks_per_row = (2 * pairs_per_row + 3) >> 2;
+	const int y = (k / blocks_per_row) * 8 + xcd;
+	const int w = (k % blocks_per_row) * 4 + wid;
+	if (y >= H || w >= 2 * pairs_per_row) return;
+	if (w < pairs_per_row) join_owner_tiles<KSTEPS, 0>(fL, fR, volL, C, D, ds, H, W, y, 2 * w, rings[wid], ablate);
+	else join_owner_tiles<KSTEPS, 1>(fL, fR, volR, C, D, ds, H, W, y, 2 * (w - pairs_per_row), rings[wid], ablate);
+}
+
 // fix_border (main.lua:922-927) on (H,W,ds): the n outermost pixels of one side replicate the
 // (n+1)-th pixel's whole cost vector.  One wave per (row, border pixel).
 __global__ void __launch_bounds__(256) fix_border_hwd_kernel(float *__restrict__ vol, int D, int ds, int H, int W, int n,
@@ -192,11 +359,26 @@ __global__ void __launch_bounds__(256) fix_border_hwd_kernel(float *__restrict__
 int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int ds, int H, int W, int n,
                     hipStream_t st)
 {
+	static const int env_join = [] { const char *e = getenv("MC_JOIN_KERNEL"); return e ? atoi(e) : 0; }();  // 1 = compute-once kernel
+	static const int env_abl = [] { const char *e = getenv("MC_JOIN_ABLATE"); return e ? atoi(e) : 0; }();
+	const int rows8 = (H + 7) / 8;
+	const int ks = (C + 1) / 2;
+	const dim3 block(256);
+	if (env_join != 1 && ds % 4 == 0 && (uintptr_t)volL % 16 == 0 && (uintptr_t)volR % 16 == 0 && ks <= 32) {
+		const int tiles_own = ((W + 31) / 32 + 1) / 2;   // pairs of 32-pixel tiles per image row and volume
+		const dim3 grid_o((unsigned)(rows8 * ((2 * tiles_own + 3) / 4) * 8));
+		if (ks <= 8) hipLaunchKernelGGL((join_owner_kernel<8>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own, env_abl);
+		else if (ks <= 16) hipLaunchKernelGGL((join_owner_kernel<16>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own, env_abl);
+		else hipLaunchKernelGGL((join_owner_kernel<32>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own, env_abl);
+		int rc = check_launch("stereo_join_hwd (owner tiles)");
+		if (rc || n <= 0) return rc;
+		hipLaunchKernelGGL(fix_border_hwd_kernel, dim3(cdiv((int64_t)H * n * 64, 256)), block, 0, st, volL, D, ds, H, W, n, -1);
+		hipLaunchKernelGGL(fix_border_hwd_kernel, dim3(cdiv((int64_t)H * n * 64, 256)), block, 0, st, volR, D, ds, H, W, n, 1);
+		return check_launch("fix_border_hwd");
+	}
 	const int tiles = (W + D - 1 + 31) / 32;  // incl. the virtual tiles right of the image (right volume's NaN triangle)
 	const int blocks_per_row = (tiles + 3) / 4;
-	const int rows8 = (H + 7) / 8;
-	const dim3 grid((unsigned)(rows8 * blocks_per_row * 8)), block(256);
-	const int ks = (C + 1) / 2;
+	const dim3 grid((unsigned)(rows8 * blocks_per_row * 8));
 #define MC_JOIN_LAUNCH(KS)                                                                                                  \
 	do {                                                                                                                    \
 		hipLaunchKernelGGL((join_mfma_kernel<KS>), grid, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles);             \
