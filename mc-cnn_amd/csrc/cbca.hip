@@ -158,8 +158,9 @@ typedef unsigned cb_u2 __attribute__((ext_vector_type(2)));
 typedef float cb_f4 __attribute__((ext_vector_type(4)));
 typedef float cb_f2 __attribute__((ext_vector_type(2)));
 
-// CS_RING rows per ring, CS_LA rows committed below (and staged above) the current output row
-template <int PF, int CS_RING, int CS_LA>
+// CS_RING rows per ring, CS_LA rows committed below (and staged above) the current output row, CS_WR column radius of
+// the window form
+template <int PF, int CS_RING, int CS_LA, int CS_WR>
 __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 {
 	constexpr int CS_UP = CS_LA;
@@ -331,19 +332,19 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 				if (e < n) {
 					const cb_u32 ent = CL[e];
 					const int c = (int)(ent & 0xffffu), u = (int)((ent >> 16) & 0xff), dn = (int)(ent >> 24);
-					// Window form: supports inside rows y-2 .. y+LA of the ring and columns x-2 .. x+2 -- nearly all of
+					// Window form: supports inside rows y-2 .. y+LA of the ring and columns x-WR .. x+WR -- nearly all of
 					// the scattered ones -- are summed from ONE batch of LDS reads: every tap of the window is read,
 					// the taps outside the support add -0.0f (x + -0.0f == x exactly, so the chain of additions is
 					// the reference's), rows ascending and x ascending as in the reference.
 					constexpr int NWR = 3 + CS_LA;
 					cb_u32 mm[NWR];
-					float tv[NWR][5];
+					float tv[NWR][2 * CS_WR + 1];
 #pragma unroll
 					for (int k = 0; k < NWR; ++k) {
 						const int ro_ = slot(yo + k - 2) * CS_COLS + c;
 						mm[k] = M[ro_];
 #pragma unroll
-						for (int t = 0; t < 5; ++t) tv[k][t] = V[ro_ + t - 2];
+						for (int t = 0; t < 2 * CS_WR + 1; ++t) tv[k][t] = V[ro_ + t - CS_WR];
 					}
 					bool ok = u <= 2 && dn <= CS_LA && yo - u >= lo_row && yo + dn <= hi_row;
 					float sum = 0;
@@ -353,13 +354,14 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 						const int rel = k - 2;
 						const bool act = rel >= -u && rel <= dn;
 						const int l = (int)(mm[k] & 0xff), rg = (int)((mm[k] >> 8) & 0xff);
-						ok = ok && (!act || (l <= 2 && rg <= 2));
+						ok = ok && (!act || (l <= CS_WR && rg <= CS_WR && c - l >= 0 && c + rg < CS_COLS));
 						const int la = act ? l : -1, rga = act ? rg : -1;   // inactive row: no tap passes
-						sum += la >= 2 ? tv[k][0] : -0.0f;
-						sum += la >= 1 ? tv[k][1] : -0.0f;
-						sum += act ? tv[k][2] : -0.0f;
-						sum += rga >= 1 ? tv[k][3] : -0.0f;
-						sum += rga >= 2 ? tv[k][4] : -0.0f;
+#pragma unroll
+						for (int t = 0; t < 2 * CS_WR + 1; ++t) {
+							const int dx = t - CS_WR;
+							const bool in = dx < 0 ? la >= -dx : (dx == 0 ? act : rga >= dx);
+							sum += in ? tv[k][t] : -0.0f;
+						}
 						cnt += act ? l + rg + 1 : 0;
 					}
 					R[c] = ok ? sum / (float)cnt : general(yo, c, u, dn, lo_row, hi_row);
@@ -448,7 +450,8 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	A.rb = env_rb > 0 ? env_rb : 40;
 	A.gx = (int)cdiv(W, CS_STEP); A.gy = (int)cdiv(H, A.rb);
 	const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(D, 4) * 4;
-	hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+	// prefetch 2 rows, ring of 4 rows, 1 row of look-ahead, window form +-2 columns (+-4 measured slower at KITTI and 1000x1500)
+	hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
 	return check_launch("cbca_strip");
 }
 
