@@ -32,6 +32,10 @@ int mc_census_ws(const float *x0, const float *x1, float *vol, int Cimg, int D, 
 int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream);
 int mc_cross(const float *img, float *arms, int H, int W, int L1, float tau1, void *stream);
 int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction, void *stream);
+size_t mc_fc_stack_workspace_bytes(int C, int n_layers, int H, int W);
+int mc_fc_stack(const float *featL, const float *featR, int C, int H, int W, int D,
+                const float *const *weights, const float *const *biases, const int *layer_out, int n_layers,
+                float *volL, float *volR, void *workspace, size_t workspace_bytes, void *stream);
 size_t mc_cbca_scratch_bytes(int H, int W);
 int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
                void *scratch, size_t scratch_bytes, void *stream);
@@ -95,11 +99,35 @@ function adcensus.StereoJoin(input_L, input_R, output_L, output_R)   -- adcensus
                             output_L:size(4), nil), 'StereoJoin')
 end
 
+-- NEW entry (no counterpart in libadcensus): the per-disparity loop of arch slow, main.lua:958-983, in one call.
+--   net_te2: the nn.Sequential of SpatialConvolution1_fw / ReLU / Sigmoid (main.lua:688-695); output: net_te.output (2,C,H,W);
+--   volL, volR: (1,disp_max,H,W) CudaTensors pre-filled with 0/0 as main.lua:968 does; both directions come out of one pass,
+--   so stereo_predict calls this once before its direction loop and skips lines 958-983 (fix_border stays, main.lua:984).
+local fc_ws = torch.CudaTensor()
+function adcensus.fc_stack(net_te2, output, volL, volR)
+   local layers = {}
+   for _, m in ipairs(net_te2.modules) do
+      if torch.typename(m) == 'nn.SpatialConvolution1_fw' then layers[#layers + 1] = m end
+   end
+   local n = #layers
+   local w = ffi.new('const float *[?]', n)
+   local b = ffi.new('const float *[?]', n)
+   local width = ffi.new('int[?]', n)
+   for i, m in ipairs(layers) do
+      w[i - 1], b[i - 1], width[i - 1] = m.weight:data(), m.bias:data(), m.weight:size(1)
+   end
+   local C, H, W, D = output:size(2), output:size(3), output:size(4), volL:size(2)
+   local need = tonumber(lib.mc_fc_stack_workspace_bytes(C, n, H, W))
+   if fc_ws:nElement() * 4 < need then fc_ws:resize(math.ceil(need / 4)) end
+   check(lib.mc_fc_stack(output[1]:data(), output[2]:data(), C, H, W, D, w, b, width, n, ptr(volL, 'fc_stack'),
+                         ptr(volR, 'fc_stack'), fc_ws:data(), fc_ws:nElement() * 4, nil), 'fc_stack')
+end
+
 function adcensus.cross(x0, out, L1, tau1)                   -- adcensus.cu:324-341
    check(lib.mc_cross(ptr(x0, 'cross'), ptr(out, 'cross'), out:size(3), out:size(4), L1, tau1, nil), 'cross')
 end
 
--- adcensus.cbca, adcensus.cu:379-400, on the LDS-tiled kernel (mc_cbca_ws); the packed arm lengths live in a
+-- adcensus.cbca, adcensus.cu:379-400, on the packed-arm strip kernel (mc_cbca_ws); the packed arm lengths live in a
 -- scratch CudaTensor this module keeps and grows on demand (same stream, so reuse across calls is ordered).
 local cbca_scratch = torch.CudaTensor()
 function adcensus.cbca(x0c, x1c, vol_in, vol_out, direction)
