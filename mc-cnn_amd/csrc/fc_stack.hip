@@ -129,28 +129,44 @@ __global__ void __launch_bounds__(256) fc_stack_kernel(const FcArgs A)
 			for (int t = 0; t < 3; ++t)
 #pragma unroll
 				for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.0f;
-		// both operands of step kk+1 are fetched before the 9 MFMAs of step kk are issued (one wave per SIMD: nothing else
-		// covers the LDS / L2 latency)
-		float bn[3], an[FC_MT];
+		// One wave per SIMD: nothing but prefetch covers latency.  The weight operand comes from L2 (a 590 KB matrix per
+		// layer, ~1 us away): it is fetched FC_BQ k-steps ahead through a register ring (every slot has one load
+		// statement in the unrolled body, so hipcc can count the loads still in flight); the activation operand comes from
+		// LDS one k-step ahead.
+		constexpr int FC_BQ = 4;
+		static_assert((FC_NH / 2) % FC_BQ == 0, "k loop shape");
+		float bq[FC_BQ][3], an[FC_MT];
+		auto load_b = [&](float (&b)[3], int kq) {
+			const int kc = kq < FC_NH / 2 ? kq : FC_NH / 2 - 1;
 #pragma unroll
-		for (int t = 0; t < 3; ++t) bn[t] = Wt[(int64_t)kh * FC_NH + n0 + 32 * t + nl];
+			for (int t = 0; t < 3; ++t) b[t] = Wt[(int64_t)(2 * kc + kh) * FC_NH + n0 + 32 * t + nl];
+		};
+#pragma unroll
+		for (int u = 0; u < FC_BQ; ++u) load_b(bq[u], u);
 #pragma unroll
 		for (int mt = 0; mt < FC_MT; ++mt) an[mt] = Ht[kh * FC_LD + 32 * mt + nl];
-		for (int kk = 0; kk < FC_NH / 2; ++kk) {
-			float bc[3], a[FC_MT];
+		for (int kk0 = 0; kk0 < FC_NH / 2; kk0 += FC_BQ) {
 #pragma unroll
-			for (int t = 0; t < 3; ++t) bc[t] = bn[t];
+			for (int u = 0; u < FC_BQ; ++u) {
+				const int kk = kk0 + u;
+				float a[FC_MT];
 #pragma unroll
-			for (int mt = 0; mt < FC_MT; ++mt) a[mt] = an[mt];
-			const int kn = kk + 1 < FC_NH / 2 ? kk + 1 : kk;
+				for (int mt = 0; mt < FC_MT; ++mt) a[mt] = an[mt];
+				const int kn = kk + 1 < FC_NH / 2 ? kk + 1 : kk;
 #pragma unroll
-			for (int t = 0; t < 3; ++t) bn[t] = Wt[(int64_t)(2 * kn + kh) * FC_NH + n0 + 32 * t + nl];
+				for (int mt = 0; mt < FC_MT; ++mt) an[mt] = Ht[(2 * kn + kh) * FC_LD + 32 * mt + nl];
+				__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-			for (int mt = 0; mt < FC_MT; ++mt) an[mt] = Ht[(2 * kn + kh) * FC_LD + 32 * mt + nl];
+				for (int mt = 0; mt < FC_MT; ++mt)
 #pragma unroll
-			for (int mt = 0; mt < FC_MT; ++mt)
-#pragma unroll
-				for (int t = 0; t < 3; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bc[t], acc[mt][t], 0, 0, 0);
+					for (int t = 0; t < 3; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bq[u][t], acc[mt][t], 0, 0, 0);
+				// the slot is consumed (its MFMAs are issued) and immediately refilled FC_BQ steps ahead: one definition per
+				// slot and no value live across it, so no copies of in-flight loads at the loop edge; the barriers keep the
+				// refill here instead of being sunk to just before its use
+				__builtin_amdgcn_sched_barrier(0);
+				load_b(bq[u], kk + FC_BQ);
+				__builtin_amdgcn_sched_barrier(0);
+			}
 		}
 		__syncthreads();  // every wave has read the whole of Ht
 		const float *__restrict__ bias = A.bh[l];
