@@ -160,10 +160,14 @@ typedef float cb_f2 __attribute__((ext_vector_type(2)));
 
 // CS_RING rows per ring, CS_LA rows committed below (and staged above) the current output row, CS_WR column radius of
 // the window form
-template <int PF, int CS_RING, int CS_LA, int CS_WR>
+template <int PF, int CS_RING, int CS_LA, int CS_WR, bool NT>
 __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 {
 	constexpr int CS_UP = CS_LA;
+	// cache policy of the volume rows: nt (bit 1) for volumes far larger than the 256 MB MALL -- streamed once, only the
+	// region's packed lengths should stay cached; smaller volumes (KITTI: 414 MB) are partly served from the MALL on the
+	// next iteration and measured faster without the hint
+	constexpr int MC_CBCA_VOL_AUX = NT ? 2 : 0;
 	auto slot = [](int r) { return (CS_RING & (CS_RING - 1)) == 0 ? (r & (CS_RING - 1)) : (int)((unsigned)(r + 4 * CS_RING) % (unsigned)CS_RING); };
 	__shared__ float Vring[4][CS_RING * CS_COLS];
 	__shared__ cb_u32 Mring[4][CS_RING * CS_COLS];
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 		const bool rok = r >= 0 && r < H;
 		const int base = r * W + xs;
 		if (full_in) {
-			st.v = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)base * 4u : OOB, 0, 0);
+			st.v = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)base * 4u : OOB, 0, MC_CBCA_VOL_AUX);
 		} else {  // strip edges: per column
 			cb_u32 t[4];
 #pragma unroll
@@ -373,7 +377,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 		const int ob = yo * W + xo;
 		if (full_out) {
 			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
-			                                       ro, (cb_u32)ob * 4u, 0, 0);
+			                                       ro, (cb_u32)ob * 4u, 0, MC_CBCA_VOL_AUX);
 		} else if (any_out) {
 #pragma unroll
 			for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[j]), ro, xo + j < W ? (cb_u32)(ob + j) * 4u : OOB, 0, 0);
@@ -451,7 +455,8 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	A.gx = (int)cdiv(W, CS_STEP); A.gy = (int)cdiv(H, A.rb);
 	const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(D, 4) * 4;
 	// prefetch 2 rows, ring of 4 rows, 1 row of look-ahead, window form +-2 columns (+-4 measured slower at KITTI and 1000x1500)
-	hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+	if ((int64_t)D * H * W * 4 > ((int64_t)768 << 20)) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+	else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
 	return check_launch("cbca_strip");
 }
 

@@ -19,6 +19,8 @@ __global__ void __launch_bounds__(256) scale_kernel(const float *__restrict__ in
 
 // out[c*ldout + r] = in[r*ldin + c] * s for an R x Cn matrix, 64x64 tiles through LDS.
 // (D,H,W)->(H,W,ds) is R=D, Cn=H*W, ldin=H*W, ldout=ds; the inverse is R=H*W, Cn=D, ldin=ds, ldout=H*W.
+// NT: non-temporal accesses for volumes far larger than the 256 MB MALL (the next kernel cannot find them there anyway)
+template <bool NT>
 __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t R,
                                                         int64_t Cn, int64_t ldin, int64_t ldout, float s)
 {
@@ -27,12 +29,15 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 	for (int k = ty; k < 64; k += 4) {
 		const int64_t r = r0 + k, c = c0 + tx;
-		if (r < R && c < Cn) tile[k][tx] = in[r * ldin + c];
+		if (r < R && c < Cn) tile[k][tx] = NT ? __builtin_nontemporal_load(in + r * ldin + c) : in[r * ldin + c];
 	}
 	__syncthreads();
 	for (int k = ty; k < 64; k += 4) {
 		const int64_t c = c0 + k, r = r0 + tx;
-		if (r < R && c < Cn) out[c * ldout + r] = tile[tx][k] * s;
+		if (r < R && c < Cn) {
+			if (NT) __builtin_nontemporal_store(tile[tx][k] * s, out + c * ldout + r);
+			else out[c * ldout + r] = tile[tx][k] * s;
+		}
 	}
 }
 
@@ -55,7 +60,8 @@ int scale(const float *in, float *out, int64_t n, float s, hipStream_t st)
 int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, int64_t ldout, float s, hipStream_t st)
 {
 	// the long axis goes to grid.x (grid.y is limited to 65535 blocks)
-	hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+	if (R * Cn * 4 > ((int64_t)768 << 20)) hipLaunchKernelGGL(transpose_kernel<true>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+	else hipLaunchKernelGGL(transpose_kernel<false>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
 	return check_launch("transpose");
 }
 
@@ -91,7 +97,7 @@ __global__ void __launch_bounds__(256) argmin_dhw_kernel(const float *__restrict
 	int argmin = 0;
 	float mn = __builtin_inff();
 	for (int i = 0; i < D; ++i) {
-		const float val = vol[i * HW + p];
+		const float val = __builtin_nontemporal_load(vol + i * HW + p);
 		if (val < mn) {
 			mn = val;
 			argmin = i;

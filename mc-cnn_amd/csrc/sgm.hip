@@ -21,6 +21,10 @@
 // disparities with VPL/4 byte loads.
 #include "mc_common.h"
 
+// cache policy of the volume accesses: nt (bit 1) -- every cost run is read or written once per sweep; streaming them keeps
+// the edge-class maps (re-read by every line) in L2
+#define MC_SGM_VOL_AUX 2
+
 namespace mc {
 
 constexpr int SGM_PADW = 520;  // >= 63*8 + 7 + slack: window starts reach -(VPL*63+VPL-1)
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__(256) sgm_pass_kernel(const SgmPassArgs A)
 		if (VEC) {
 #pragma unroll
 			for (int q = 0; q < VPL / 4; ++q) {
-				const uint4v t = __builtin_amdgcn_raw_buffer_load_b128(r, (dbase + 4 * q) * 4, 0, 0);
+				const uint4v t = __builtin_amdgcn_raw_buffer_load_b128(r, (dbase + 4 * q) * 4, 0, MC_SGM_VOL_AUX);
 				dst[4 * q + 0] = __uint_as_float(t.x); dst[4 * q + 1] = __uint_as_float(t.y);
 				dst[4 * q + 2] = __uint_as_float(t.z); dst[4 * q + 3] = __uint_as_float(t.w);
 			}
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(256) sgm_pass_kernel(const SgmPassArgs A)
 				uint4v t;
 				t.x = __float_as_uint(o[4 * q + 0]); t.y = __float_as_uint(o[4 * q + 1]);
 				t.z = __float_as_uint(o[4 * q + 2]); t.w = __float_as_uint(o[4 * q + 3]);
-				__builtin_amdgcn_raw_buffer_store_b128(t, r, (dbase + 4 * q) * 4, 0, 0);
+				__builtin_amdgcn_raw_buffer_store_b128(t, r, (dbase + 4 * q) * 4, 0, MC_SGM_VOL_AUX);
 			}
 		} else {
 #pragma unroll

@@ -183,6 +183,10 @@ __global__ void __launch_bounds__(256) join_mfma_kernel(const float *__restrict_
 // extend that pixel's run contiguously.  They are parked in a 64-float LDS ring per pixel; after every tile the
 // 128-byte LINES of the volume that have become complete are written, 8 lanes x 16 bytes per line -- full, aligned
 // lines only, apart from the first and last line of a pixel's run.
+// cache policy of the volume stores: nt (bit 1) -- the 2 V of output stream through L2 once and must not push the image
+// row's features (re-read by every wave of the row) out of it
+#define MC_JOIN_STORE_AUX 2
+
 template <int KSTEPS, int SIDE>
 __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, const float *__restrict__ fR, float *__restrict__ vol,
                                                  int C, int D, int ds, int H, int W, int y, int tile0, float *__restrict__ rings, int ablate)
@@ -295,12 +299,12 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 			// (unsigned)d0 < ds  <=>  the piece holds at least one d of [0, D) of THIS pixel (d0 % 4 == 0, ds = D rounded up to 4)
 			const float4 v = *(const float4 *)(ring + fro + (d0 & 63));
 			__builtin_amdgcn_raw_buffer_store_b128((cb_u4_t){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
-			                                       rrow, (unsigned)d0 < (unsigned)ds ? fgo[t][pass] + (unsigned)d0 * 4u : OOBF, 0, 0);
+			                                       rrow, (unsigned)d0 < (unsigned)ds ? fgo[t][pass] + (unsigned)d0 * 4u : OOBF, 0, MC_JOIN_STORE_AUX);
 			if (last) {
 				const int d1 = d0 + 32;
 				const float4 u = *(const float4 *)(ring + fro + (d1 & 63));
 				__builtin_amdgcn_raw_buffer_store_b128((cb_u4_t){__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(u.z), __float_as_uint(u.w)},
-				                                       rrow, (unsigned)d1 < (unsigned)ds ? fgo[t][pass] + (unsigned)d1 * 4u : OOBF, 0, 0);
+				                                       rrow, (unsigned)d1 < (unsigned)ds ? fgo[t][pass] + (unsigned)d1 * 4u : OOBF, 0, MC_JOIN_STORE_AUX);
 			}
 		}
 	};

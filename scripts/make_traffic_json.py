@@ -19,7 +19,7 @@ def main(d, config):
             if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean over dispatches; source: " + d}
-    groups = {"sgm": "sgm_pass_kernel", "cbca": "cbca_strip_kernel", "join": "join_mfma_kernel", "transpose": "transpose_kernel"}
+    groups = {"sgm": "sgm_pass_kernel", "cbca": "cbca_strip_kernel", "join": "join_owner_kernel", "transpose": "transpose_kernel"}
     for g, pat in groups.items():
         ks = [k for k in acc if pat in k]
         if not ks:
