@@ -128,7 +128,7 @@ struct CbcaArgs {
 	int D, H, W, direction;
 	int rb;                       // output rows per strip
 	const uint32_t *overflow;     // optional: set by cbca_pack when an arm saturated the packed form -> do nothing
-	int ablate;                   // tuning aid (MC_CBCA_ABLATE): 1 = skip the larger supports, 2 = copy through
+	int ablate;                   // tuning aid (MC_CBCA_ABLATE): 1 = skip the larger supports, 2 = copy through, 4 = window form only
 	int gx, gy;                   // strips per row, row chunks
 };
 
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 						}
 						cnt += act ? l + rg + 1 : 0;
 					}
-					R[c] = ok ? sum / (float)cnt : general(yo, c, u, dn, lo_row, hi_row);
+					R[c] = (ok || (A.ablate & 4)) ? sum / (float)cnt : general(yo, c, u, dn, lo_row, hi_row);
 				}
 			}
 			const cb_f2 r0 = *(const cb_f2 *)(R + c0 + 2), r1 = *(const cb_f2 *)(R + c1 + (lane < 63 ? 0 : 2));
