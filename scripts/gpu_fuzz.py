@@ -1,0 +1,56 @@
+"""Randomised parity sweep (tuning / confidence aid): mc_predict (fused) against the CPU oracle on random shapes, parameter
+tables, image kinds and stage switches; bit-exact on every output or the case is printed.
+    python scripts/gpu_fuzz.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import mc_cnn_amd as mc
+from oracle import cpu_oracle as oracle
+from util import smooth_pair, blocky_pair, random_pair, features, raw_volumes  # noqa: E402
+
+from util import same_bits as same
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+names = sorted(mc.PRESETS)
+bad = 0
+t0 = time.time()
+for it in range(n):
+    name = names[rng.integers(len(names))]
+    prm = dict(mc.PRESETS[name])
+    big_d = rng.random() < 0.15
+    H = int(rng.integers(3, 40 if big_d else 90))
+    W = int(rng.integers(6, 120 if big_d else 560))
+    D = int(rng.integers(2, min(W, 300 if big_d else 70)))
+    prm["cbca_i1"] = int(min(prm["cbca_i1"], 2)); prm["cbca_i2"] = int(min(prm["cbca_i2"], 3))
+    if rng.random() < 0.3:
+        prm["sm_terminate"] = ["", "cnn", "cbca1", "sgm", "cbca2", "subpixel_enchancement", "median", "bilateral"][rng.integers(8)]
+    if rng.random() < 0.3:
+        prm["sm_skip"] = ["", "cbca", "sgm", "occlusion", "subpixel_enchancement", "median", "bilateral"][rng.integers(7)]
+    kind = ["smooth", "blocky", "random"][rng.integers(3)]
+    x0, x1 = (smooth_pair(H, W, min(D, 8), seed=it) if kind == "smooth" else blocky_pair(H, W, seed=it) if kind == "blocky"
+              else random_pair(H, W, seed=it))
+    xb = torch.from_numpy(np.stack([x0, x1])).cuda()[:, None]
+    from_feat = rng.random() < 0.5
+    if from_feat:
+        C = int(rng.choice([1, 3, 8, 16, 31, 64, 70, 112]))
+        f = features(C, H, W, seed=it)
+        prm["border_n"] = int(rng.integers(0, 5))
+        want = oracle.stereo_predict(prm, x0, x1, D, featL=f[0], featR=f[1])
+        kw = dict(feat=torch.from_numpy(f).cuda())
+    else:
+        C = 0
+        vl, vr = raw_volumes(D, H, W, seed=it)
+        want = oracle.stereo_predict(prm, x0, x1, D, rawL=vl, rawR=vr)
+        kw = dict(raw=(torch.from_numpy(vl).cuda(), torch.from_numpy(vr).cuda()))
+    got = mc.stereo_predict_fused(xb, prm, D, want_volumes=True, want_disp0=True, **kw)
+    torch.cuda.synchronize()
+    fails = [k for k in ("volL", "volR", "dispL0", "dispR0", "disp") if not same(got[k].cpu().numpy(), want[k])]
+    if fails:
+        bad += 1
+        print("MISMATCH", fails, dict(name=name, H=H, W=W, D=D, C=C, kind=kind, sm_terminate=prm.get("sm_terminate"), sm_skip=prm.get("sm_skip"),
+                                      border_n=prm.get("border_n")), flush=True)
+print("fuzz: %d cases, %d mismatching, %.0f s" % (n, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
