@@ -398,6 +398,40 @@ def test_main_predict_hand_crafted_costs(mc, oracle, tmp_path, monkeypatch, arch
     assert_same(mc.read_bin("disp.bin", (1, 1, H, W)), want["disp"], "disp.bin")
 
 
+def test_predict_kitti_end_to_end(mc, oracle, tmp_path, capsys):
+    """`predict_kitti.py test` over two synthetic KITTI-layout pairs: the printed mean 3-pixel error is the one of the
+    disparity maps the oracle produces for the same features."""
+    from PIL import Image
+    from scipy.ndimage import gaussian_filter
+    from mc_cnn_amd import binio, main as mcmain, predict_kitti as pk
+    root = tmp_path / "unzip"
+    for sub in ("training/image_0", "training/image_1", "training/disp_noc"):
+        (root / sub).mkdir(parents=True)
+    H, W, D = 30, 80, 12
+    rng = np.random.default_rng(4)
+    want_errs = []
+    layers = mcmain.load_net("random:7", "kitti", "fast")
+    prm = dict(mc.TABLES[("kitti", "fast")])
+    prm["border_n"] = len(layers)
+    for i in range(2):
+        base = gaussian_filter(rng.random((H, W + 6)), 2.0)
+        base = ((base - base.min()) / np.ptp(base) * 255).astype(np.uint8)
+        Image.fromarray(base[:, 6:]).save(root / ("training/image_0/%06d_10.png" % i))
+        Image.fromarray(base[:, :W]).save(root / ("training/image_1/%06d_10.png" % i))
+        gt = np.full((H, W), 6.0, np.float32)
+        gt[:, :10] = 0
+        binio.write_png16(gt, str(root / ("training/disp_noc/%06d_10.png" % i)))
+        x0 = mcmain.normalize(mcmain.load_image(str(root / ("training/image_0/%06d_10.png" % i))))
+        x1 = mcmain.normalize(mcmain.load_image(str(root / ("training/image_1/%06d_10.png" % i))))
+        feat = host(mcmain.features_fast(dev(np.stack([x0, x1])), layers))
+        disp = oracle.stereo_predict(prm, x0[0], x1[0], D, featL=feat[0], featR=feat[1])["disp"].reshape(H, W)
+        want_errs.append(pk.three_pixel_error(disp, binio.read_png16(str(root / ("training/disp_noc/%06d_10.png" % i)))))
+    assert pk.main(["test", "-path", str(root), "-net_fname", "random:7", "-disp_max", str(D), "-n", "2"]) == 0
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert [float(l.split()[1]) for l in lines[:2]] == want_errs
+    assert abs(float(lines[-1]) - sum(want_errs) / 2) < 1e-12
+
+
 def test_errors_are_loud(mc):
     """Bad arguments raise (reference: Lua error), they never fall back."""
     t = torch.zeros((1, 4, 8, 8), device="cuda")

@@ -250,3 +250,49 @@ def test_png16_and_pfm_follow_adcensus(tmp_path):
     raw = open(q, "rb").read()
     head = b"Pf\n4 2\n-0.003922\n"
     assert raw.startswith(head) and np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(2, 4), d)
+
+
+def test_predict_kitti_host_logic(tmp_path):
+    """predict_kitti.lua:40-83 on the host side: file layout, PNG16 ground truth, 3-pixel error, sharding, submit files."""
+    from PIL import Image
+    from mc_cnn_amd import binio, predict_kitti as pk
+    root = tmp_path / "unzip"
+    for d in ("training/image_0", "training/image_1", "training/disp_noc", "testing/image_0", "testing/image_1"):
+        (root / d).mkdir(parents=True)
+    H, W = 6, 9
+    rng = np.random.default_rng(0)
+    gts = []
+    for i in range(3):
+        for cam in (0, 1):
+            Image.fromarray(rng.integers(0, 255, (H, W), dtype=np.uint8)).save(root / ("training/image_%d/%06d_10.png" % (cam, i)))
+            Image.fromarray(rng.integers(0, 255, (H, W), dtype=np.uint8)).save(root / ("testing/image_%d/%06d_10.png" % (cam, i)))
+        gt = rng.integers(0, 40, (H, W)).astype(np.float32)
+        gt[rng.random((H, W)) < 0.3] = 0            # no ground truth
+        binio.write_png16(gt, str(root / ("training/disp_noc/%06d_10.png" % i)))
+        gts.append(gt)
+    assert pk.pair_paths("p", "submit", 7) == ("p/testing/image_0/000007_10.png", "p/testing/image_1/000007_10.png")
+    seen = []
+
+    def fake_predict(im0, im1):                      # ground truth shifted by 5 where the left image is bright
+        i = int(os.path.basename(im0)[:6])
+        seen.append(i)
+        left = np.asarray(Image.open(im0)).astype(np.float32)
+        return gts[i] + np.where(left > 128, 5.0, 1.0).astype(np.float32)
+
+    import os
+    logs = []
+    total, done = pk.run("test", str(root), fake_predict, n_pairs=3, log=lambda *a: logs.append(a))
+    assert done == 3 and seen == [0, 1, 2] and [a[0] for a in logs] == [0, 1, 2]
+    want = 0.0
+    for i in range(3):
+        left = np.asarray(Image.open(root / ("training/image_0/%06d_10.png" % i)))
+        m = gts[i] != 0
+        want += ((left > 128) & m).sum() / m.sum()
+    assert abs(total - want) < 1e-12
+    # two ranks split the pairs; each writes its own submission files
+    seen.clear()
+    for r in (0, 1):
+        pk.run("submit", str(root), fake_predict, world=2, rank=r, out_dir=str(tmp_path / "out"), n_pairs=3, log=lambda *a: None)
+    assert sorted(seen) == [0, 1, 2] and sorted(p.name for p in (tmp_path / "out").iterdir()) == ["%06d_10.png" % i for i in range(3)]
+    back = binio.read_png16(str(tmp_path / "out" / "000001_10.png"))
+    assert back.shape == (H, W)
