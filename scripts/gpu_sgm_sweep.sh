@@ -2,7 +2,7 @@
 # SGM prefetch-depth sweep (tuning aid): per-kernel average time of the three sweeps per (UH, UD, UU), rocprofv3 kernel trace
 O=$GRAFT_REPO_ROOT/gpurun_out/sgmsweep; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for combo in "8 4 4" "16 8 8" "8 4 16" "4 16 8"; do
+for combo in "4 16 4" "8 16 4" "4 16 8" "4 8 4" "16 16 4"; do
   set -- $combo
   rm -rf $O/p
   MC_SGM_UH=$1 MC_SGM_UD=$2 MC_SGM_UU=$3 timeout 300 rocprofv3 --kernel-trace --stats -d $O/p -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ref-gpu > $O/log 2>&1
