@@ -1,0 +1,41 @@
+"""bench.py pieces that need no GPU: the algorithmic-bytes model is SURVEY.md section 8(d)'s, the workload table names
+BASELINE.json's configurations, and the default workload is configs[1]."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_algorithmic_bytes_follow_survey_8d():
+    b = _bench()
+    import mc_cnn_amd as mc
+    H, W, D, C = 370, 1226, 228, 64
+    V, F = 4.0 * D * H * W, 4.0 * C * H * W
+    fast = b.algorithmic_bytes(dict(mc.PRESETS["kitti_fast"]), H, W, D, C)
+    assert fast["join"] == 2 * F + 2 * V            # read both feature maps, write both volumes
+    assert fast["sgm"] == 2 * 11 * V                # 11 V per volume and sgm2 call
+    assert fast["cbca"] == 0 and fast["argmin"] == 2 * V
+    slow = b.algorithmic_bytes(dict(mc.PRESETS["mb_slow"]), 1000, 1500, 256, 0)
+    Vm = 4.0 * 256 * 1000 * 1500
+    assert slow["join"] == 0 and slow["cbca"] == 2 * (2 + 16) * 2 * Vm   # 2 V per iteration and volume
+    assert abs(slow["total"] - (slow["cbca"] + slow["sgm"] + slow["argmin"])) < 1
+
+
+def test_workloads_are_baseline_configs():
+    b = _bench()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert b.CONFIGS["kitti_fast"][1:4] == (370, 1226, 228) and "KITTI 2012 fast" in base["configs"][1]
+    assert b.CONFIGS["kitti_slow"][1:4] == (370, 1226, 228) and "accurate" in base["configs"][2]
+    assert b.CONFIGS["mb_slow"][1:4] == (1000, 1500, 256) and "1500x1000" in base["configs"][3]
+    assert b.HBM_PEAK_GBS == 8000.0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'default="kitti_fast"' in src          # BASELINE configs[1] is what `python bench.py` measures
+    assert base["metric"].startswith("Mega-pixel-disparities/sec")
