@@ -3,6 +3,7 @@
 #include "mc_common.h"
 
 #include <stdarg.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -38,7 +39,7 @@ int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, h
 int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
                      int direction, hipStream_t st);
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
-               hipStream_t st);
+               hipStream_t st, int d0 = 0, int nd = 0);
 size_t fc_workspace_bytes(int C, int n_hidden, int H, int W);
 int fc_stack(const float *featL, const float *featR, int C, int H, int W, int D, const float *const *weights,
              const float *const *biases, int n_layers, float *volL, float *volR, void *workspace, hipStream_t st);
@@ -222,6 +223,37 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	const float *cur[2];
 	auto other = [&](int v) -> float * { return cur[v] == bufA[v] ? bufB[v] : bufA[v]; };
 	bool hwd;  // layout of cur[]
+	// n CBCA iterations on both (D,H,W) volumes, ping-pong between the two buffers of each side.  With several iterations
+	// the planes are processed in slabs: all iterations of a slab of planes run back to back, so that iteration i+1 finds
+	// the planes iteration i wrote in the 256 MB Infinity Cache instead of HBM (planes are independent in CBCA).
+	auto cbca_iterations = [&](int n) -> int {
+		if (n <= 0) return 0;
+		static const int env_slab = [] { const char *e = getenv("MC_CBCA_SLAB_MB"); return e ? atoi(e) : 0; }();
+		const bool strips = cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096;  // packed lengths saturate at 255
+		int slab = D;
+		if (strips && n > 1 && env_slab > 0) slab = (int)std::max<int64_t>(4, std::min<int64_t>(D, ((int64_t)env_slab << 20) / (HW * 4) / 4 * 4));
+		for (int v = 0; v < 2; ++v) {
+			const float *src0 = cur[v];
+			float *a = other(v);                                    // iteration 1 writes here
+			float *b = (src0 == bufA[v] || src0 == bufB[v]) ? (float *)src0 : (a == bufA[v] ? bufB[v] : bufA[v]);
+			for (int d0 = 0; d0 < D; d0 += slab) {
+				const int nd = std::min(slab, D - d0);
+				const float *src = src0;
+				float *dst = a;
+				for (int i = 0; i < n; ++i) {
+					int rc2;
+					if (strips) rc2 = cbca_strips(packed, src, dst, D, H, W, direction[v], cbca_cap, st, d0, nd);
+					else rc2 = cbca(x0c, x1c, src, dst, D, H, W, direction[v], st);
+					if (rc2) return rc2;
+					src = dst;
+					dst = (dst == a) ? b : a;
+				}
+				if (!strips) break;  // the direct kernel handles the whole volume per launch
+			}
+			cur[v] = (n % 2) ? a : b;
+		}
+		return 0;
+	};
 	// the MFMA StereoJoin addresses one image row of a volume and one feature map with 32-bit byte offsets
 	const bool join_fits = (int64_t)W * ((D + 3) / 4 * 4) * 4 < ((int64_t)1 << 31) && ((int64_t)C * HW + W) * 4 < ((int64_t)1 << 31);
 	if (from_feat && n_cbca1 == 0 && n_sgm > 0 && join_fits) {
@@ -243,14 +275,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		}
 		hwd = false;
 		tm.mark(ST_JOIN);
-		for (int i = 0; i < n_cbca1; ++i) {  // main.lua:998-1001 (ping-pong instead of vol:copy(tmp))
-			for (int v = 0; v < 2; ++v) {
-				float *dst = other(v);
-				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096) RUN(cbca_strips(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
-				else RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));  // packed lengths saturate at 255
-				cur[v] = dst;
-			}
-		}
+		RUN(cbca_iterations(n_cbca1));  // main.lua:998-1001 (ping-pong instead of vol:copy(tmp))
 		tm.mark(ST_CBCA);
 	}
 
@@ -290,14 +315,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		}
 	}
 	if (!hwd) {  // CBCA-2, main.lua:1033-1039
-		for (int i = 0; i < n_cbca2; ++i) {
-			for (int v = 0; v < 2; ++v) {
-				float *dst = other(v);
-				if (cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096) RUN(cbca_strips(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st));
-				else RUN(cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st));  // packed lengths saturate at 255
-				cur[v] = dst;
-			}
-		}
+		RUN(cbca_iterations(n_cbca2));
 		tm.mark(ST_CBCA);
 	}
 
