@@ -9,16 +9,26 @@ LR check -> interpolation -> sub-pixel -> median -> range-gated Gaussian) with t
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config kitti_fast|kitti_slow|mb_slow]
 
 Default workload = BASELINE.json configs[1]: KITTI 2012 fast, 370x1226, disp_max 228.
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank processes its own pair
-per step (weak scaling, pairs are independent) and the finished disparity maps are gathered
-with one RCCL all-gather per step -- the only collective on the path.
+N > 1: one rank per GPU (launched by torch.distributed.run, or spawned by this script itself when
+WORLD_SIZE is not set); every rank processes its own pair per step (weak scaling, pairs are
+independent) and the finished disparity maps are gathered with one RCCL all-gather per step --
+the only collective on the path.
 
 Prints ONE JSON line (rank 0).  `value` = Mega-pixel-disparities / s = n_gpus * 2 volumes *
-H*W*D / 1e6 / seconds-per-step.
+H*W*D / 1e6 / seconds-per-step.  Beside the contract's fields the line carries
+  roofline      the kernel group with the largest MEASURED time among those with a byte model
+                (StereoJoin / CBCA / SGM), + `kernels`: all of them
+  verify        the timed configuration's outputs bit-compared with main.lua's stereo_predict over
+                the REFERENCE'S OWN kernels (oracle/_ref) on the same GPU and inputs
+  north_star    (default run, N=1) the 1000x1500x256 accurate configuration: ms/pair, the per-volume
+                SGM + cross-aggregation sweep against SURVEY 8(d)'s 47 V budget, and its own verify
+  cpu_baseline  the oracle on the host cores (min of 3)
+  ops_ms_per_pair  the unchanged-main.lua route: the same pair through the op-by-op adcensus.* calls
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,6 +48,11 @@ CONFIGS = {
     "tiny": ("kitti_fast", 48, 160, 32, 16, "tiny plumbing case"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+KERNEL_NAMES = {
+    "join": "join_owner_kernel (StereoJoin on v_mfma_f32_32x32x2_f32, both volumes, NaN fill + fix_border folded in)",
+    "cbca": "cbca_strip_kernel (one launch per iteration and volume)",
+    "sgm": "sgm_pass_kernel (right+left sweep, down sweep, up sweep: 3 launches over both volumes)",
+}
 
 
 def algorithmic_bytes(preset, H, W, D, C):
@@ -50,6 +65,16 @@ def algorithmic_bytes(preset, H, W, D, C):
              argmin=2 * V)
     b["total"] = sum(b.values())
     return b
+
+
+def launches_per_step(preset, C):
+    return {"join": 1 if C else 0, "cbca": 2 * (preset["cbca_i1"] + preset["cbca_i2"]), "sgm": 3 * preset["sgm_i"]}
+
+
+def pick_dominant(stage_ms, ab):
+    """The kernel group that takes the most measured time among those SURVEY 8(d) gives a byte model for."""
+    cands = [k for k in ("join", "cbca", "sgm") if ab.get(k, 0) > 0 and stage_ms.get(k, 0) > 0]
+    return max(cands, key=lambda k: stage_ms[k]) if cands else None
 
 
 def make_inputs(cfg, rank, device):
@@ -79,56 +104,175 @@ def make_inputs(cfg, rank, device):
     return xb, kw, host
 
 
-def cpu_baseline(cfg, host, budget_rows):
+def same_bits_dev(a, b):
+    """bit-exact equality on the device with NaN == NaN (NaN masks must match)"""
+    import torch
+    a, b = a.reshape(-1), b.reshape(-1)
+    if a.shape != b.shape:
+        return False
+    na, nb = torch.isnan(a), torch.isnan(b)
+    bad = (na != nb) | (~na & (a.view(torch.int32) != b.view(torch.int32)))
+    return not bool(bad.any().item())
+
+
+def verify_against_reference(cfg, xb, kw, prm, D, ws, cfg_key):
+    """Outputs of the timed call form (+ the exported volumes and arg-min maps) against main.lua's stereo_predict run
+    over the reference's own kernels (oracle/_ref, test infrastructure) on this GPU, bit for bit."""
+    import torch
+    import mc_cnn_amd as mc
+    try:
+        from oracle.ref_lib import RefLib
+        from ref_pipeline import ref_stereo_predict
+        ref = RefLib()
+    except Exception as e:  # not built (needs /root/reference at build time)
+        return dict(vs="oracle/_ref", available=False, reason=str(e)[:160], bit_exact=None, config=cfg_key)
+    preset, H, W, _, C, _ = cfg
+    args = dict(feat=kw["feat"]) if C > 0 else dict(raw=kw["raw"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    want = ref_stereo_predict(ref, prm, xb, D, **args)
+    torch.cuda.synchronize()
+    ref_ms = (time.perf_counter() - t0) * 1e3
+    got = mc.stereo_predict_fused(xb, prm, D, workspace=ws, want_volumes=True, want_disp0=True, **args)
+    out = torch.empty((1, 1, H, W), dtype=torch.float32, device=xb.device)
+    mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, **args)   # exactly the call the timed loop makes
+    torch.cuda.synchronize()
+    fields = {}
+    for key, label in (("volL", "left.bin"), ("volR", "right.bin"), ("dispL0", "argmin_left"), ("dispR0", "argmin_right"),
+                       ("disp", "disp.bin")):
+        fields[label] = same_bits_dev(got[key], want[key])
+    fields["disp.bin (timed call)"] = same_bits_dev(out, want["disp"])
+    return dict(vs="oracle/_ref (the reference's adcensus.cu compiled for gfx950, driven as main.lua:929-1082 does)",
+                available=True, bit_exact=all(fields.values()), fields=fields, config=cfg_key,
+                shape=[H, W, D], reference_ms_per_pair=round(ref_ms, 1))
+
+
+def cpu_baseline(cfg, host, budget_rows, runs=3):
     """The oracle (a faithful CPU restatement of the reference, oracle/mc_oracle.c) on a bounded
-    sample of the same workload: a band of `rows` image rows at full width and full disp_max."""
+    sample of the same workload: a band of `rows` image rows at full width and full disp_max; min of `runs`."""
     from oracle import cpu_oracle
     import mc_cnn_amd as mc
     preset, H, W, D, C, _ = cfg
     rows = min(H, budget_rows)
     prm = dict(mc.PRESETS[preset])
     x0, x1 = host["x0"][:rows], host["x1"][:rows]
-    kw = {}
     if C:
         kw = dict(featL=host["feat"][0][:, :rows], featR=host["feat"][1][:, :rows])
     else:
         kw = dict(rawL=host["raw"][0][:, :rows], rawR=host["raw"][1][:, :rows])
     cpu_oracle.build()
-    t0 = time.perf_counter()
-    cpu_oracle.stereo_predict(prm, x0, x1, D, **kw)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        cpu_oracle.stereo_predict(prm, x0, x1, D, **kw)
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
     cores = int(os.environ.get("OMP_NUM_THREADS", cores))
     return dict(value=round(2.0 * rows * W * D / 1e6 / dt, 3), unit="MPix-disp/s", cores=cores, kind="port",
-                sample="oracle stereo_predict on a %dx%dx%d band (%d of %d rows) of the same pair, 1 run, %.1f s" %
-                       (rows, W, D, rows, H, dt))
+                sample="oracle stereo_predict on a %dx%dx%d band (%d of %d rows) of the same pair, min of %d runs (%s s)" %
+                       (rows, W, D, rows, H, runs, "/".join("%.1f" % t for t in times)))
 
 
-def reference_on_gpu(cfg, xb, kw, prm, D):
-    """The reference's OWN kernels (oracle/_ref: /root/reference/adcensus.cu compiled for gfx950, test
-    infrastructure) driven through main.lua's stereo_predict sequence on the same inputs and the same GPU:
-    one warm-up + one timed run.  Reported beside the product's number, never part of it."""
+def stage_times(step, reps):
+    acc = {}
+    for _ in range(reps):
+        r = step(timed=True)
+        for k, v in r["stage_ms"].items():
+            acc[k] = acc.get(k, 0.0) + v / reps
+    acc.pop("_", None)
+    return acc
+
+
+def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step):
+    ab = algorithmic_bytes(prm, H, W, D, max(C, 0))
+    nl = launches_per_step(prm, max(C, 0))
+    traffic_all = {}
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % cfg_key)
+    if os.path.exists(tfile):
+        traffic_all = json.load(open(tfile))
+    kernels = {}
+    for k in ("join", "cbca", "sgm"):
+        if ab[k] > 0 and acc.get(k, 0) > 0:
+            gbs = ab[k] / (acc[k] * 1e-3) / 1e9
+            kernels[k] = dict(ms=round(acc[k], 4), launches=nl[k], algorithmic_GB=round(ab[k] / 1e9, 3),
+                              achieved_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+    dom = pick_dominant(acc, ab)
+    if dom is None:
+        return None
+    achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9
+    return dict(bound="hbm", kernel=KERNEL_NAMES[dom], picked_by="largest measured stage time", achieved=round(achieved, 1),
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic_all.get(dom),
+                launches_per_step=nl[dom], algorithmic_bytes_per_launch=round(ab[dom] / nl[dom]),
+                avg_launch_ms=round(acc[dom] / nl[dom], 4), kernels=kernels,
+                pipeline_frac=round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+
+
+def north_star_record(device, steps=5):
+    """BASELINE.json north_star: the SGM + cross-aggregation sweep at 1500x1000x256 (mb-slow parameters,
+    main.lua:132-144: 2 + 16 CBCA iterations), per volume, against SURVEY 8(d)'s 47 V = 72.2 GB budget."""
     import torch
-    try:
-        from oracle.ref_lib import RefLib, RefUnavailable
-        from ref_pipeline import ref_stereo_predict
-        ref = RefLib()
-    except Exception as e:  # not built (needs /root/reference at build time)
-        return dict(available=False, reason=str(e)[:120])
-    preset, H, W, _, C, _ = cfg
-    args = dict(feat=kw["feat"]) if C else dict(raw=kw["raw"])
-    ref_stereo_predict(ref, prm, xb, D, **args)
+    import mc_cnn_amd as mc
+    from mc_cnn_amd.predict import Workspace
+    cfg = CONFIGS["mb_slow"]
+    preset, H, W, D, C, name = cfg
+    prm = dict(mc.PRESETS[preset])
+    xb, kw, _ = make_inputs(cfg, 0, device)
+    ws = Workspace(prm, D, H, W, device)
+    out = torch.empty((1, 1, H, W), dtype=torch.float32, device=device)
+
+    def step(timed=False):
+        return mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, timed=timed, **kw)
+    for _ in range(2):  # the first pass over a fresh 9 GB workspace pays its page mapping
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ref_stereo_predict(ref, prm, xb, D, **args)
+    for _ in range(steps):
+        step()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return dict(available=True, ms_per_pair=round(dt * 1e3, 2), value=round(2.0 * H * W * D / 1e6 / dt, 1),
-                unit="MPix-disp/s", kind="reference kernels (hipcc build of adcensus.cu) + torch glue, same MI355X",
-                note="2W+2H sgm2 launches per volume as in adcensus.cu:639-693; includes host launch overhead")
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    acc = stage_times(step, 3)
+    V = 4.0 * D * H * W
+    n_it = prm["cbca_i1"] + prm["cbca_i2"]
+    sweep_ms = (acc.get("cbca", 0) + acc.get("sgm", 0)) / 2          # per volume
+    layout_ms = acc.get("layout", 0) / 2
+    budget = (2 * n_it + 11) * V
+    rec = dict(workload=name, H=H, W=W, disp_max=D, cbca_iterations=n_it, ms_per_pair=round(ms, 3),
+               value_MPix_disp_s=round(2.0 * H * W * D / 1e6 / (ms * 1e-3), 1),
+               stage_ms={k: round(v, 3) for k, v in acc.items()},
+               per_volume=dict(cbca_ms=round(acc.get("cbca", 0) / 2, 3), sgm_ms=round(acc.get("sgm", 0) / 2, 3),
+                               layout_ms=round(layout_ms, 3), algorithmic_GB=round(budget / 1e9, 2),
+                               sweep_ms=round(sweep_ms, 3),
+                               frac_of_hbm_peak=round(budget / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               frac_incl_layout=round(budget / ((sweep_ms + layout_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               target=0.70),
+               roofline=roofline_record("mb_slow", prm, H, W, D, C, acc, ms),
+               verify=verify_against_reference(cfg, xb, kw, prm, D, ws, "mb_slow"))
+    del ws, xb, kw
+    torch.cuda.empty_cache()
+    return rec
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    return rc
 
 
 def main():
@@ -139,8 +283,13 @@ def main():
     ap.add_argument("--config", default="kitti_fast", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline band (0 = auto)")
-    ap.add_argument("--no-ref-gpu", action="store_true", help="skip timing the reference's own kernels on this GPU")
+    ap.add_argument("--no-ref-gpu", action="store_true", help="skip the verify leg (reference's own kernels on this GPU)")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the 1000x1500x256 sub-record of the default run")
+    ap.add_argument("--no-ops", action="store_true", help="skip timing the op-by-op (unchanged main.lua) route")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -150,10 +299,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" %
-              (args.gpus, args.gpus), file=sys.stderr)
-        sys.exit(2)
     # MC_BENCH_ONE_GPU=1 (plumbing check on a 1-GPU box only): every rank uses cuda:0 and the collectives run over gloo
     one_gpu = os.environ.get("MC_BENCH_ONE_GPU") == "1"
     dev_index = 0 if one_gpu else local_rank
@@ -192,15 +337,19 @@ def main():
             return mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, raw=cost_volume(), timed=timed)
         return mc.stereo_predict_fused(xb, prm, D, workspace=ws, out=out, timed=timed, **kw)
 
+    def gather():
+        # the path's only exchange: finished disparity maps (H*W*4 B per GPU) over xGMI
+        if one_gpu:
+            parts = [torch.empty((1, H, W)) for _ in range(world)]
+            dist.all_gather(parts, out.view(1, H, W).cpu())
+            gathered.copy_(torch.cat(parts).to(device))
+        else:
+            dist.all_gather_into_tensor(gathered, out.view(1, H, W))
+
     def step_untimed():
         step()
-        if world > 1:  # the path's only exchange: finished disparity maps (H*W*4 B per GPU) over xGMI
-            if one_gpu:
-                parts = [torch.empty((1, H, W)) for _ in range(world)]
-                dist.all_gather(parts, out.view(1, H, W).cpu())
-            else:
-                dist.all_gather_into_tensor(gathered, out.view(1, H, W))
-
+        if world > 1:
+            gather()
 
     def sync():
         if world > 1:
@@ -222,39 +371,50 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * 2.0 * H * W * D / 1e6 / (dt / args.steps)
 
-    # live per-stage HIP-event timing (same stream) for the roofline of the dominant kernel
-    roof = None
-    stage = None
+    # ---- multi-rank bookkeeping: who took part, and is the gathered batch what the ranks computed ----
+    multi = None
+    if world > 1:
+        ids = torch.tensor([rank], dtype=torch.int64, device="cpu" if one_gpu else device)
+        seen = [torch.zeros_like(ids) for _ in range(world)]
+        dist.all_gather(seen, ids)
+        ranks_seen = sorted(int(s.item()) for s in seen)
+        step()
+        gather()
+        torch.cuda.synchronize()
+        own_ok = same_bits_dev(gathered[rank], out)            # every rank: its slot holds its own result
+        flag = torch.tensor([1 if own_ok else 0], dtype=torch.int64, device="cpu" if one_gpu else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        checked, others_ok = [], True
+        if rank == 0 and fc_ws is None:
+            # rank 0 recomputes the pairs of up to two other ranks on its own GPU: the gathered maps must equal
+            # what a single-GPU run produces for those pairs
+            for r in sorted({1, world - 1}):
+                xb_r, kw_r, _ = make_inputs(cfg, r, device)
+                o = mc.stereo_predict_fused(xb_r, prm, D, workspace=ws, **kw_r)["disp"]
+                torch.cuda.synchronize()
+                others_ok = others_ok and same_bits_dev(gathered[r], o)
+                checked.append(r)
+                del xb_r, kw_r
+        multi = dict(ranks_seen=ranks_seen, world_size=world, backend="gloo (MC_BENCH_ONE_GPU)" if one_gpu else "nccl (RCCL)",
+                     own_slot_bit_exact_all_ranks=bool(flag.item()), ranks_recomputed_on_rank0=checked,
+                     gathered_equals_single_gpu=bool(others_ok))
+
+    # live per-stage HIP-event timing (same stream) for the roofline
+    roof = stage = None
+    acc = {}
     if rank == 0:
         reps = max(3, min(10, args.steps))
-        acc = {}
-        for _ in range(reps):
-            if fc_ws is not None:  # the FC stack runs before mc_predict: time it with events on the same stream
+        if fc_ws is not None:  # the FC stack runs before mc_predict: time it with events on the same stream
+            for _ in range(reps):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 cost_volume()
                 e1.record()
                 torch.cuda.synchronize()
                 acc["fc_stack"] = acc.get("fc_stack", 0.0) + e0.elapsed_time(e1) / reps
-            r = step(timed=True)
-            for k, v in r["stage_ms"].items():
-                acc[k] = acc.get(k, 0.0) + v / reps
-        stage = {k: round(v, 4) for k, v in acc.items() if k != "_"}
-        ab = algorithmic_bytes(prm, H, W, D, max(C, 0))
-        dom = "cbca" if ab["cbca"] > ab["sgm"] else "sgm"
-        n_launch = {"sgm": 3 * prm["sgm_i"], "cbca": 2 * (prm["cbca_i1"] + prm["cbca_i2"])}[dom]
-        achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9 if acc[dom] > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(dom)
-        roof = dict(bound="hbm", kernel={"sgm": "sgm_pass_kernel (right+left sweep, down sweep, up sweep: 3 launches over both volumes)",
-                                         "cbca": "cbca_strip_kernel (one launch per iteration per volume)"}[dom],
-                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=traffic, launches_per_step=n_launch,
-                    algorithmic_bytes_per_launch=round(ab[dom] / n_launch),
-                    avg_launch_ms=round(acc[dom] / n_launch, 4),
-                    pipeline_frac=round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        acc.update(stage_times(step, reps))
+        stage = {k: round(v, 4) for k, v in acc.items()}
+        roof = roofline_record(args.config, prm, H, W, D, C, acc, ms_per_step)
 
     if rank == 0 and fc_ws is not None and roof is not None:
         # the accurate net's dominant kernel is the FC stack: a dense fp32 GEMM chain on the matrix cores
@@ -264,21 +424,34 @@ def main():
         tf = flop / (acc["fc_stack"] * 1e-3) / 1e12
         roof = dict(bound="mfma", kernel="fc_stack_kernel (+ fc_project_kernel): both volumes from one pass", achieved=round(tf, 1),
                     peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4), traffic=None, launches_per_step=1,
-                    algorithmic_flops_per_launch=flop, avg_launch_ms=round(acc["fc_stack"], 3),
+                    algorithmic_flops_per_launch=flop, avg_launch_ms=round(acc["fc_stack"], 3), kernels=roof.get("kernels"),
                     note="fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense peak); layer 1 is evaluated as two per-pixel "
                          "projections, so the executed flops are 16 % below the reference's count used here")
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.config == "kitti_slow_fc":
-            cpu = None  # the oracle's FC stack is a scalar triple loop (hours at this size); see kitti_slow for the pipeline's CPU baseline
-        else:
-            rows = args.cpu_rows or {"kitti_fast": 370, "kitti_slow": 370, "mb_slow": 8, "tiny": 48}[args.config]
-            cpu = cpu_baseline(cfg, host, rows)
+    verify = ops_ms = None
+    if rank == 0 and world == 1 and fc_ws is None:
+        if not args.no_ref_gpu:
+            verify = verify_against_reference(cfg, xb, kw, prm, D, ws, args.config)
+        if not args.no_ops:
+            # the route an unchanged main.lua takes through the shim: ~25 adcensus.* calls + tensor glue per pair
+            mc.stereo_predict(xb, prm, D, **kw)
+            torch.cuda.synchronize()
+            n = 3
+            t0 = time.perf_counter()
+            for _ in range(n):
+                mc.stereo_predict(xb, prm, D, **kw)
+            torch.cuda.synchronize()
+            ops_ms = round((time.perf_counter() - t0) / n * 1e3, 3)
 
-    refgpu = None
-    if rank == 0 and world == 1 and not args.no_ref_gpu and args.config in ("kitti_fast", "kitti_slow", "tiny"):
-        refgpu = reference_on_gpu(cfg, xb, kw, prm, D)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "kitti_slow_fc":
+        # (kitti_slow_fc: the oracle's FC stack is a scalar triple loop, hours at this size; see kitti_slow)
+        rows = args.cpu_rows or {"kitti_fast": 370, "kitti_slow": 370, "mb_slow": 8, "tiny": 48}[args.config]
+        cpu = cpu_baseline(cfg, host, rows)
+
+    north = None
+    if rank == 0 and world == 1 and args.config == "kitti_fast" and not args.no_north_star:
+        north = north_star_record(device)
 
     if rank == 0:
         line = {
@@ -289,9 +462,11 @@ def main():
             "config": {"workload": cfg_name, "H": H, "W": W, "disp_max": D, "feature_channels": abs(C),
                        "params": preset_name, "pairs_per_step": world, "parallelism": "one pair per GPU",
                        "end_to_end_ms_per_pair": round(ms_per_step, 4)},
-            "stage_ms": stage, "roofline": roof, "cpu_baseline": cpu, "reference_on_gpu": refgpu,
+            "stage_ms": stage, "roofline": roof, "cpu_baseline": cpu, "verify": verify, "ops_ms_per_pair": ops_ms,
+            "multi_gpu": multi, "north_star": north,
         }
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -37,7 +37,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define MC_ABI_VERSION 2
+#define MC_ABI_VERSION 3
 #define MC_EINVAL (-22)
 #define MC_SGM_MAX_D 512   /* reference: __shared__ float[400], adcensus.cu:574 */
 #define MC_JOIN_MAX_C 128  /* reference: float L_cache[128], adcensus.cu:1460-1461 */
@@ -61,12 +61,11 @@ int mc_stereo_join(const float *featL, const float *featR, float *volL, float *v
 /* adcensus.ad(x0, x1, out, direction), adcensus.cu:95-114 (kernel 62-93). x: (H,W). */
 int mc_ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, void *stream);
 
-/* adcensus.census(x0, x1, out, direction), adcensus.cu:155-175 (kernel 117-153). x: (Cimg,H,W). */
-int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W,
-              int direction, void *stream);
-
-/* The same operator from per-pixel census signatures (81 comparison bits per pixel and channel, computed once
- * instead of once per disparity) held in `scratch` (mc_census_scratch_bytes); bit-identical to mc_census. */
+/* adcensus.census(x0, x1, out, direction), adcensus.cu:155-175 (kernel 117-153). x: (Cimg,H,W).  Computed from
+ * per-pixel census signatures (the 81 comparison bits of a pixel's 9x9 window per channel do not depend on the
+ * disparity: they are packed once per image into `scratch`, mc_census_scratch_bytes, and a voxel's cost is the
+ * reference's count of out-of-bounds taps plus a popcount of differing bits) -- the same small integers as the
+ * reference's 81 comparisons per voxel. */
 size_t mc_census_scratch_bytes(int Cimg, int H, int W);
 int mc_census_ws(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W,
                  int direction, void *scratch, size_t scratch_bytes, void *stream);
@@ -98,9 +97,12 @@ int mc_cross(const float *img, float *arms, int H, int W, int L1, float tau1, vo
 int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
             int D, int H, int W, int direction, void *stream);
 
-/* The same operator on the fast path: arm lengths are packed into `scratch` (mc_cbca_scratch_bytes) and the
- * region sums run out of LDS-staged tiles; same accumulation order, bit-identical to mc_cbca.  Tiles whose
- * arms exceed the staged halo (16 pixels here) fall back to mc_cbca's loop inside the same launch. */
+/* The same operator on the fast path: the per-arm minimum lengths of the two images are packed into `scratch`
+ * (mc_cbca_scratch_bytes, 4 bytes per pixel and image) and one wave walks a strip of 256 staged columns of one
+ * disparity plane top to bottom (rows in registers / a wave-private LDS ring, no block barrier); same accumulation
+ * order, bit-identical to mc_cbca.  Supports that leave the staged rows or columns are summed from global memory by
+ * the same wave; an arm longer than 254 pixels (not representable in the packed form) makes the call fall back to
+ * mc_cbca's kernel inside the same call. */
 size_t mc_cbca_scratch_bytes(int H, int W);
 int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
                int D, int H, int W, int direction, void *scratch, size_t scratch_bytes, void *stream);
@@ -194,6 +196,9 @@ typedef struct mc_params {
 	int median_k;      /* 5, main.lua:1073 */
 	int sm_terminate;  /* -sm_terminate <stage>: MC_SM_* below, 0 = run everything (main.lua:25,988-1075) */
 	int sm_skip;       /* -sm_skip <stage>: MC_SKIP_* below, 0 = skip nothing (main.lua:26,992-1077) */
+	int left_only;     /* 1 = direction -1 only where the reference does so: dataset mb outside `-a predict`
+	                      (mb_directions, main.lua:953-955); ignored when lr_check = 1 or a right-side output is
+	                      requested.  0 = both directions, as `-a predict` computes them */
 } mc_params;
 
 /* -sm_terminate stages, in pipeline order (the stereo method stops being "active" after the named stage) */
@@ -241,6 +246,25 @@ int mc_predict_timed(const mc_params *p, const float *x0, const float *x1,
                      const float *rawL, const float *rawR, int D, int H, int W,
                      void *workspace, size_t workspace_bytes, float *disp_out, void *stream,
                      float *stage_ms);
+
+/* ---- test / bench hooks (not part of the reference's surface) ---------------- */
+
+/* mc_cbca_ws with the launch geometry forced instead of derived from the problem size: rows per strip `rb` (0 = auto),
+ * cache policy `nt` (-1 = auto, 0 = default policy, 1 = non-temporal volume accesses), planes [d0, d0+nd) only
+ * (nd = 0: all).  Lets small-shape parity tests reach the instantiations the benchmarked sizes select. */
+int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
+                   int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
+                   int rb, int nt, int d0, int nd, void *stream);
+
+/* (H,W,D)<->(D,H,W) transpose with the cache policy forced (nt as above); scale multiplies every element. */
+int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, int64_t ldin, int64_t ldout,
+                     float scale, int nt, void *stream);
+
+/* Walks `count` consecutive float bit patterns from `first` on the device and compares the three-operation division
+ * by 9 used by the cbca kernels with the IEEE quotient.  counters (DEVICE, 3 x uint64, zeroed by the caller):
+ * [0] mismatches inside the guarded magnitude range (must stay 0), [1] mismatches outside it (handled by the IEEE
+ * divide at run time), [2] one offending bit pattern. */
+int mc_selftest_div9(uint32_t first, uint64_t count, unsigned long long *counters, void *stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -10,12 +10,13 @@ LIB_PATH = os.path.join(_HERE, "libmcadcensus.so")
 
 # every symbol include/mc_adcensus.h declares
 SYMBOLS = [
-    "mc_version", "mc_last_error", "mc_fill_nan", "mc_stereo_join", "mc_ad", "mc_census", "mc_census_scratch_bytes", "mc_census_ws", "mc_fc_stack_workspace_bytes", "mc_fc_stack",
+    "mc_version", "mc_last_error", "mc_fill_nan", "mc_stereo_join", "mc_ad", "mc_census_scratch_bytes", "mc_census_ws", "mc_fc_stack_workspace_bytes", "mc_fc_stack",
     "mc_fix_border",
     "mc_cross", "mc_cbca", "mc_cbca_scratch_bytes", "mc_cbca_ws", "mc_sgm2_tmp_bytes", "mc_sgm2", "mc_dhw_to_hwd", "mc_hwd_to_dhw", "mc_scale",
     "mc_argmin", "mc_spatial_argmin", "mc_outlier_detection", "mc_interpolate_occlusion",
     "mc_interpolate_mismatch", "mc_subpixel_enchancement", "mc_median2d", "mc_mean2d", "mc_gaussian_host",
     "mc_normalize_forward", "mc_predict_workspace_bytes", "mc_predict", "mc_predict_timed",
+    "mc_cbca_ws_cfg", "mc_transpose_cfg", "mc_selftest_div9",
 ]
 
 
@@ -39,7 +40,6 @@ def _load():
         "mc_fill_nan": [vp, i64, vp],
         "mc_stereo_join": [vp, vp, vp, vp, i, i, i, i, vp],
         "mc_ad": [vp, vp, vp, i, i, i, i, vp],
-        "mc_census": [vp, vp, vp, i, i, i, i, i, vp],
         "mc_census_scratch_bytes": [i, i, i],
         "mc_census_ws": [vp, vp, vp, i, i, i, i, i, vp, sz, vp],
         "mc_fc_stack_workspace_bytes": [i, i, i, i],
@@ -67,6 +67,9 @@ def _load():
         "mc_predict": [C.POINTER(McParams), vp, vp, vp, vp, i, vp, vp, i, i, i, vp, sz, vp, vp, vp, vp, vp, vp],
         "mc_predict_timed": [C.POINTER(McParams), vp, vp, vp, vp, i, vp, vp, i, i, i, vp, sz, vp, vp,
                              C.POINTER(C.c_float)],
+        "mc_cbca_ws_cfg": [vp, vp, vp, vp, i, i, i, i, vp, sz, i, i, i, i, vp],
+        "mc_transpose_cfg": [vp, vp, i64, i64, i64, i64, f, i, vp],
+        "mc_selftest_div9": [C.c_uint32, C.c_uint64, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -74,7 +77,7 @@ def _load():
         if name not in ("mc_sgm2_tmp_bytes", "mc_cbca_scratch_bytes", "mc_census_scratch_bytes",
                         "mc_fc_stack_workspace_bytes"):
             fn.restype = C.c_int
-    if lib.mc_version() != 2:
+    if lib.mc_version() != 3:
         raise ImportError("mc-cnn_amd: ABI version mismatch")
     return lib
 

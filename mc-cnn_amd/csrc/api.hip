@@ -13,7 +13,7 @@ namespace mc {
 // kernels.hip units
 int fill_nan(float *p, int64_t n, hipStream_t st);
 int scale(const float *in, float *out, int64_t n, float s, hipStream_t st);
-int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, int64_t ldout, float s, hipStream_t st);
+int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, int64_t ldout, float s, hipStream_t st, int nt = -1);
 int fix_border(float *vol, int D, int H, int W, int n, int direction, hipStream_t st);
 int argmin_dhw(const float *vol, float *out, int D, int H, int W, int base1, hipStream_t st);
 int argmin_hwd(const float *vol, float *out, int D, int ds, int H, int W, hipStream_t st);
@@ -27,7 +27,6 @@ int normalize_forward(const float *in, float *norm, float *out, int N, int C, in
 int stereo_join_dhw(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int H, int W, hipStream_t st);
 int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int ds, int H, int W, int n,
                     hipStream_t st);
-int census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, hipStream_t st);
 int ad_tiled(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, hipStream_t st);
 size_t census_scratch_bytes(int Cimg, int H, int W);
 int census_sig(const float *x0, const float *x1, float *vol, void *scratch, int Cimg, int D, int H, int W, int direction,
@@ -39,7 +38,8 @@ int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, h
 int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
                      int direction, hipStream_t st);
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
-               hipStream_t st, int d0 = 0, int nd = 0);
+               hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
+int div9_selftest(uint32_t first, uint64_t count, unsigned long long *counters, hipStream_t st);
 size_t fc_workspace_bytes(int C, int n_hidden, int H, int W);
 int fc_stack(const float *featL, const float *featR, int C, int H, int W, int D, const float *const *weights,
              const float *const *biases, int n_layers, float *volL, float *volR, void *workspace, hipStream_t st);
@@ -72,27 +72,40 @@ int check_launch(const char *what)
 
 static bool dims_ok(int D, int H, int W) { return D >= 1 && H >= 1 && W >= 1 && (int64_t)D * H * W < ((int64_t)1 << 40); }
 
-// gaussian(sigma), main.lua:528-540, double on the host.  Cached per sigma; vectors are never
-// freed so that an in-flight async upload never sees its source disappear.
-static const std::vector<float> &gaussian_cached(double sigma)
+// gaussian(sigma), main.lua:528-540, double on the host.  Cached per sigma in PINNED host memory (allocated once, never
+// freed), so that the per-call upload into the workspace is a true asynchronous copy that never sees its source disappear.
+static void gaussian_fill(double sigma, float *k)
 {
-	static std::mutex mu;
-	static std::map<double, std::vector<float> *> cache;
-	std::lock_guard<std::mutex> lk(mu);
-	auto it = cache.find(sigma);
-	if (it != cache.end()) return *it->second;
 	const int kr = (int)ceil(sigma * 3);
 	const int ks = kr * 2 + 1;
-	auto *k = new std::vector<float>((size_t)ks * ks);
 	for (int i = 1; i <= ks; ++i) {
 		for (int j = 1; j <= ks; ++j) {
 			const double y = (i - 1) - kr;
 			const double x = (j - 1) - kr;
-			(*k)[(size_t)(i - 1) * ks + (j - 1)] = (float)exp(-(x * x + y * y) / (2 * sigma * sigma));
+			k[(size_t)(i - 1) * ks + (j - 1)] = (float)exp(-(x * x + y * y) / (2 * sigma * sigma));
 		}
 	}
-	cache[sigma] = k;
-	return *k;
+}
+struct GaussianK { const float *data; size_t n; };
+static int gaussian_cached(double sigma, GaussianK &out)
+{
+	static std::mutex mu;
+	static std::map<double, GaussianK> cache;
+	std::lock_guard<std::mutex> lk(mu);
+	auto it = cache.find(sigma);
+	if (it != cache.end()) { out = it->second; return 0; }
+	const int kr = (int)ceil(sigma * 3);
+	const int ks = kr * 2 + 1;
+	float *k = nullptr;
+	const hipError_t e = hipHostMalloc((void **)&k, (size_t)ks * ks * sizeof(float), hipHostMallocDefault);
+	if (e != hipSuccess) {
+		set_error("gaussian: hipHostMalloc: %s", hipGetErrorString(e));
+		return (int)e;
+	}
+	gaussian_fill(sigma, k);
+	out = GaussianK{k, (size_t)ks * ks};
+	cache[sigma] = out;
+	return 0;
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -167,6 +180,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	           "mc_predict: bad sm_terminate / sm_skip");
 	const bool from_feat = featL != nullptr;
 	if (from_feat) MC_REQUIRE(p->border_n >= 0 && p->border_n < W, "mc_predict: border_n=%d out of range", p->border_n);
+	if (from_feat) MC_REQUIRE(C <= MC_JOIN_MAX_C, "mc_predict: C=%d exceeds %d (adcensus.cu:1460)", C, MC_JOIN_MAX_C);
 	const Plan pl = make_plan(p, D, H, W);
 	MC_REQUIRE(workspace_bytes >= pl.total, "mc_predict: workspace %zu < %zu bytes", workspace_bytes, pl.total);
 	MC_REQUIRE((uintptr_t)workspace % 256 == 0, "mc_predict: workspace must be 256-byte aligned");
@@ -223,38 +237,23 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	const float *cur[2];
 	auto other = [&](int v) -> float * { return cur[v] == bufA[v] ? bufB[v] : bufA[v]; };
 	bool hwd;  // layout of cur[]
-	// n CBCA iterations on both (D,H,W) volumes, ping-pong between the two buffers of each side.  With several iterations
-	// the planes are processed in slabs: all iterations of a slab of planes run back to back, so that iteration i+1 finds
-	// the planes iteration i wrote in the 256 MB Infinity Cache instead of HBM (planes are independent in CBCA).
+	// direction +1 (the right volume) is skipped where the reference skips it: dataset mb outside `-a predict`
+	// (mb_directions, main.lua:953-955) -- only when nothing of it is asked for
+	const int nvol = (p->left_only && !p->lr_check && !volR_out && !dispR0_out) ? 1 : 2;
+	// n CBCA iterations on the (D,H,W) volumes, ping-pong between the two buffers of each side (instead of vol:copy(tmp))
 	auto cbca_iterations = [&](int n) -> int {
-		if (n <= 0) return 0;
-		static const int env_slab = [] { const char *e = getenv("MC_CBCA_SLAB_MB"); return e ? atoi(e) : 0; }();
 		const bool strips = cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096;  // packed lengths saturate at 255
-		int slab = D;
-		if (strips && n > 1 && env_slab > 0) slab = (int)std::max<int64_t>(4, std::min<int64_t>(D, ((int64_t)env_slab << 20) / (HW * 4) / 4 * 4));
-		for (int v = 0; v < 2; ++v) {
-			const float *src0 = cur[v];
-			float *a = other(v);                                    // iteration 1 writes here
-			float *b = (src0 == bufA[v] || src0 == bufB[v]) ? (float *)src0 : (a == bufA[v] ? bufB[v] : bufA[v]);
-			for (int d0 = 0; d0 < D; d0 += slab) {
-				const int nd = std::min(slab, D - d0);
-				const float *src = src0;
-				float *dst = a;
-				for (int i = 0; i < n; ++i) {
-					int rc2;
-					if (strips) rc2 = cbca_strips(packed, src, dst, D, H, W, direction[v], cbca_cap, st, d0, nd);
-					else rc2 = cbca(x0c, x1c, src, dst, D, H, W, direction[v], st);
-					if (rc2) return rc2;
-					src = dst;
-					dst = (dst == a) ? b : a;
-				}
-				if (!strips) break;  // the direct kernel handles the whole volume per launch
+		for (int i = 0; i < n; ++i) {
+			for (int v = 0; v < nvol; ++v) {
+				float *dst = other(v);
+				const int rc2 = strips ? cbca_strips(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st)
+				                       : cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st);
+				if (rc2) return rc2;
+				cur[v] = dst;
 			}
-			cur[v] = (n % 2) ? a : b;
 		}
 		return 0;
 	};
-	// the MFMA StereoJoin addresses one image row of a volume and one feature map with 32-bit byte offsets
 	const bool join_fits = (int64_t)W * ((D + 3) / 4 * 4) * 4 < ((int64_t)1 << 31) && ((int64_t)C * HW + W) * 4 < ((int64_t)1 << 31);
 	if (from_feat && n_cbca1 == 0 && n_sgm > 0 && join_fits) {
 		// fast path: StereoJoin straight into (H,W,ds) with NaN fill and fix_border folded in
@@ -284,7 +283,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	bool have_disp = false;
 	if (n_sgm > 0) {
 		if (!hwd) {  // vol:transpose(2,3):transpose(3,4):clone(), main.lua:1008
-			for (int v = 0; v < 2; ++v) {
+			for (int v = 0; v < nvol; ++v) {
 				float *dst = other(v);
 				RUN(transpose(cur[v], dst, D, HW, HW, ds, 1.0f, st));
 				cur[v] = dst;
@@ -298,14 +297,14 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 			const float *Cv[2] = {cur[0], cur[1]};
 			float *outv[2] = {other(0), other(1)};
 			const bool am = (it == n_sgm - 1) && n_cbca2 == 0;
-			RUN(sgm_sweeps(Cv, outv, bufC, am ? dispv : nullptr, direction, 2, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
+			RUN(sgm_sweeps(Cv, outv, bufC, am ? dispv : nullptr, direction, nvol, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
 			               p->sgm_q1, p->sgm_q2, true, st));
 			have_disp = am;
 			cur[0] = outv[0]; cur[1] = outv[1];
 		}
 		tm.mark(ST_SGM);
 		if (n_cbca2 > 0) {  // back to (D,H,W): vol:copy(out:transpose(3,4):transpose(2,3)), main.lua:1019-1020
-			for (int v = 0; v < 2; ++v) {
+			for (int v = 0; v < nvol; ++v) {
 				float *dst = other(v);
 				RUN(transpose(cur[v], dst, HW, D, ds, HW, 1.0f, st));
 				cur[v] = dst;
@@ -321,14 +320,14 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 
 	// ---- argmin, main.lua:1049-1050 ----
 	if (!have_disp) {
-		for (int v = 0; v < 2; ++v) {
+		for (int v = 0; v < nvol; ++v) {
 			if (hwd) RUN(argmin_hwd(cur[v], dispv[v], D, ds, H, W, st));
 			else RUN(argmin_dhw(cur[v], dispv[v], D, H, W, 0, st));
 		}
 	}
 	// ---- left.bin / right.bin contents, main.lua:1042-1047 ----
 	float *vout[2] = {volL_out, volR_out};
-	for (int v = 0; v < 2; ++v) {
+	for (int v = 0; v < nvol; ++v) {
 		if (!vout[v]) continue;
 		if (hwd) RUN(transpose(cur[v], vout[v], HW, D, ds, HW, 1.0f, st));
 		else RUN(scale(cur[v], vout[v], V, 1.0f, st));
@@ -379,9 +378,10 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	}
 	sm_active = sm_active && p->sm_terminate != MC_SM_MEDIAN;
 	if (sm_active && p->sm_skip != MC_SKIP_BILATERAL) {
-		const std::vector<float> &k = gaussian_cached(p->blur_sigma);
+		GaussianK k;
+		RUN(gaussian_cached(p->blur_sigma, k));
 		const int ks = 2 * (int)ceil(p->blur_sigma * 3) + 1;
-		const hipError_t e = hipMemcpyAsync(gk, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice, st);
+		const hipError_t e = hipMemcpyAsync(gk, k.data, k.n * sizeof(float), hipMemcpyHostToDevice, st);  // pinned source
 		if (e != hipSuccess) {
 			set_error("mc_predict: kernel upload: %s", hipGetErrorString(e));
 			return (int)e;
@@ -427,14 +427,6 @@ int mc_ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int
 	MC_REQUIRE(direction == -1 || direction == 1, "mc_ad: direction must be -1 or 1");
 	MC_REQUIRE(D <= 65535, "mc_ad: D too large");
 	return ad_tiled(x0, x1, vol, D, H, W, direction, as_stream(stream));
-}
-
-int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, void *stream)
-{
-	MC_REQUIRE(x0 && x1 && vol, "mc_census: null pointer");
-	MC_REQUIRE(dims_ok(D, H, W) && Cimg >= 1, "mc_census: bad dims");
-	MC_REQUIRE(direction == -1 || direction == 1, "mc_census: direction must be -1 or 1");
-	return census(x0, x1, vol, Cimg, D, H, W, direction, as_stream(stream));
 }
 
 size_t mc_census_scratch_bytes(int Cimg, int H, int W)
@@ -529,6 +521,44 @@ int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *v
 	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st);
 	if (rc) return rc;
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
+}
+
+int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
+                   void *scratch, size_t scratch_bytes, int rb, int nt, int d0, int nd, void *stream)
+{
+	MC_REQUIRE(x0c && x1c && vol_in && vol_out && scratch, "mc_cbca_ws_cfg: null pointer");
+	MC_REQUIRE(vol_in != vol_out, "mc_cbca_ws_cfg: in-place aggregation is not supported");
+	MC_REQUIRE(dims_ok(D, H, W) && D <= 65535 * 8, "mc_cbca_ws_cfg: bad dims");
+	MC_REQUIRE(direction == -1 || direction == 1, "mc_cbca_ws_cfg: direction must be -1 or 1");
+	MC_REQUIRE(scratch_bytes >= cbca_scratch_bytes(H, W), "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu", scratch_bytes,
+	           cbca_scratch_bytes(H, W));
+	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
+	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws_cfg: image too large for 32-bit plane offsets");
+	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1, "mc_cbca_ws_cfg: bad rb / nt");
+	MC_REQUIRE(d0 >= 0 && nd >= 0 && d0 + nd <= D, "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
+	hipStream_t st = as_stream(stream);
+	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
+	if (rc) return rc;
+	CbcaCfg cfg;
+	cfg.rb = rb; cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd;
+	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg);
+	if (rc) return rc;
+	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
+}
+
+int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, int64_t ldin, int64_t ldout, float scale_, int nt,
+                     void *stream)
+{
+	MC_REQUIRE(in && out && in != out, "mc_transpose_cfg: bad pointers");
+	MC_REQUIRE(rows >= 1 && cols >= 1 && ldin >= cols && ldout >= rows, "mc_transpose_cfg: bad dims");
+	MC_REQUIRE(nt >= -1 && nt <= 1, "mc_transpose_cfg: bad nt");
+	return transpose(in, out, rows, cols, ldin, ldout, scale_, as_stream(stream), nt);
+}
+
+int mc_selftest_div9(uint32_t first, uint64_t count, unsigned long long *counters, void *stream)
+{
+	MC_REQUIRE(counters && count >= 1 && count <= ((uint64_t)1 << 32), "mc_selftest_div9: bad arguments");
+	return div9_selftest(first, count, counters, as_stream(stream));
 }
 
 size_t mc_sgm2_tmp_bytes(int H, int W, int D)
@@ -639,11 +669,10 @@ int mc_mean2d(const float *img, const float *kernel, float *out, int H, int W, i
 int mc_gaussian_host(double sigma, float *host_kernel, int capacity)
 {
 	MC_REQUIRE(sigma > 0, "mc_gaussian_host: sigma must be > 0");
-	const std::vector<float> &k = gaussian_cached(sigma);
 	const int ks = 2 * (int)ceil(sigma * 3) + 1;
-	if (host_kernel) {
+	if (host_kernel) {  // plain host arithmetic: works without a device
 		MC_REQUIRE(capacity >= ks * ks, "mc_gaussian_host: capacity %d < %d", capacity, ks * ks);
-		for (size_t i = 0; i < k.size(); ++i) host_kernel[i] = k[i];
+		gaussian_fill(sigma, host_kernel);
 	}
 	return ks;
 }

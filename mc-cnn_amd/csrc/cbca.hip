@@ -129,7 +129,6 @@ struct CbcaArgs {
 	int D, H, W, direction;
 	int rb;                       // output rows per strip
 	const uint32_t *overflow;     // optional: set by cbca_pack when an arm saturated the packed form -> do nothing
-	int ablate;                   // tuning aid (MC_CBCA_ABLATE): 1 = skip the larger supports, 2 = copy through, 4 = window form only
 	int gx, gy;                   // strips per row, row chunks
 	int d0, nd;                   // planes [d0, d0 + nd) of the volume are processed by this launch
 };
@@ -314,11 +313,10 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 			sum += rb_[j + 1]; sum += rb_[j + 2]; sum += rb_[j + 3];
 			sum += rc_[j + 1]; sum += rc_[j + 2]; sum += rc_[j + 3];
 			const bool inr = (inr_mask >> j) & 1u;
-			res[j] = (inr && !(A.ablate & 2)) ? sum / 9.0f : rb_[j + 2];   // adcensus.cu:353-354: copied through
+			res[j] = inr ? sum / 9.0f : rb_[j + 2];   // adcensus.cu:353-354: copied through
 			if (t != 0) needmask |= 1u << j;
 		}
 		needmask &= inr_mask & valid_mask;
-		if (A.ablate & 1) needmask = 0;
 		if (__any(needmask != 0)) {
 			// compact the (lane, j) pairs that need the general loop into CL[0..n)
 			int n = 0;
@@ -370,7 +368,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 						}
 						cnt += act ? l + rg + 1 : 0;
 					}
-					R[c] = (ok || (A.ablate & 4)) ? sum / (float)cnt : general(yo, c, u, dn, lo_row, hi_row);
+					R[c] = ok ? sum / (float)cnt : general(yo, c, u, dn, lo_row, hi_row);
 				}
 			}
 			const cb_f2 r0 = *(const cb_f2 *)(R + c0 + 2), r1 = *(const cb_f2 *)(R + c1 + (lane < 63 ? 0 : 2));
@@ -767,38 +765,29 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
 
 // max_arm: largest arm length that can occur (L1-1 when L1 is known, else < 0: the pack kernel's overflow flag decides).
 // Arm lengths saturate at 255 in the packed form: callers route max_arm > 254 to the direct kernel.
-int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm, hipStream_t st, int d0, int nd)
+// cfg (mc_common.h): rows per strip, cache policy and plane range; zero / negative fields = derived from the size.
+int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm, hipStream_t st,
+                const CbcaCfg &cfg)
 {
-	if (nd <= 0) { d0 = 0; nd = D; }
-	static const int env_abl = [] { const char *e = getenv("MC_CBCA_ABLATE"); return e ? atoi(e) : 0; }();  // tuning aids
-	static const int env_rb = [] { const char *e = getenv("MC_CBCA_RB"); return e ? atoi(e) : 0; }();
+	const int d0 = cfg.nd > 0 ? cfg.d0 : 0, nd = cfg.nd > 0 ? cfg.nd : D;
 	CbcaArgs A;
 	const CbcaScratch cs = cbca_scratch(packed, H, W);
 	A.p0 = cs.p0; A.p1 = cs.p1;
 	A.vin = vin; A.vout = vout;
 	A.D = D; A.H = H; A.W = W; A.direction = direction;
 	A.d0 = d0; A.nd = nd;
-	A.ablate = env_abl;
 	A.overflow = max_arm < 0 ? cs.flag : nullptr;  // unknown arm bound: honour cbca_pack's flag
 	A.gx = (int)cdiv(W, CS_STEP);
 	// output rows per strip: 40 (5 % of halo rows) unless that leaves fewer than ~16 K waves -- at KITTI size (5 strips x
 	// 228 planes) 27 and 20 rows measured 5 % faster than 40, 53 rows 18 % slower
 	const int64_t gy_min = cdiv((int64_t)16384, (int64_t)A.gx * nd);
 	const int rb_auto = (int)std::min<int64_t>(40, std::max<int64_t>(16, cdiv((int64_t)H, gy_min)));
-	A.rb = env_rb > 0 ? env_rb : rb_auto;
+	A.rb = cfg.rb > 0 ? cfg.rb : rb_auto;
 	A.gy = (int)cdiv(H, A.rb);
 	const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(nd, 4) * 4;
+	// non-temporal volume accesses for volumes far larger than the 256 MB Infinity Cache (see cbca_strip_kernel)
+	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
 	// prefetch 2 rows, ring of 4 rows, 1 row of look-ahead, window form +-2 columns (+-4 measured slower at KITTI and 1000x1500)
-	static const int env_nt = [] { const char *e = getenv("MC_CBCA_NT"); return e ? atoi(e) : -1; }();
-	const bool nt = env_nt >= 0 ? env_nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
-	static const int env_v2 = [] { const char *e = getenv("MC_CBCA_V2"); return e ? atoi(e) : 0; }();
-	if (env_v2) {
-		A.gx = (int)cdiv(W, C2_STEP);
-		const int64_t waves2 = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(nd, 4) * 4;
-		if (nt) hipLaunchKernelGGL((cbca_strip2_kernel<4, 1, 2, true>), dim3((unsigned)cdiv(waves2, 4)), dim3(256), 0, st, A);
-		else hipLaunchKernelGGL((cbca_strip2_kernel<4, 1, 2, false>), dim3((unsigned)cdiv(waves2, 4)), dim3(256), 0, st, A);
-		return check_launch("cbca_strip2");
-	}
 	if (nt) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
 	else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
 	return check_launch("cbca_strip");

@@ -25,6 +25,13 @@ int check_launch(const char *what);  // hipPeekAtLastError -> rc, like checkCuda
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// launch configuration of the cbca strip kernels; the defaults derive everything from the problem size
+struct CbcaCfg {
+	int rb = 0;        // output rows per strip (0 = auto)
+	int nt = -1;       // volume cache policy: -1 auto, 0 default, 1 non-temporal
+	int d0 = 0, nd = 0;// planes [d0, d0 + nd) only (nd = 0: all)
+};
+
 // ---- wave64 cross-lane primitives (DPP, no LDS round trip) -------------------
 // gfx9 DPP controls.
 constexpr int DPP_QUAD_1032 = 0xB1;        // quad_perm:[1,0,3,2]

@@ -57,10 +57,11 @@ int scale(const float *in, float *out, int64_t n, float s, hipStream_t st)
 	return check_launch("scale");
 }
 
-int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, int64_t ldout, float s, hipStream_t st)
+int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, int64_t ldout, float s, hipStream_t st, int nt)
 {
 	// the long axis goes to grid.x (grid.y is limited to 65535 blocks)
-	if (R * Cn * 4 > ((int64_t)768 << 20)) hipLaunchKernelGGL(transpose_kernel<true>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+	const bool use_nt = nt >= 0 ? nt != 0 : R * Cn * 4 > ((int64_t)768 << 20);
+	if (use_nt) hipLaunchKernelGGL(transpose_kernel<true>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
 	else hipLaunchKernelGGL(transpose_kernel<false>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
 	return check_launch("transpose");
 }

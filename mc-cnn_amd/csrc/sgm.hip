@@ -334,17 +334,6 @@ int sgm_prep(const float *x0, const float *x1, void *maps, int H, int W, float t
 	return check_launch("sgm_prep");
 }
 
-static int sgm_depth(int dirn, int deflt)
-{
-	// MC_SGM_UH / MC_SGM_UD / MC_SGM_UU = <4|8|16> override the prefetch depth of the horizontal / down / up sweeps
-	// (tuning aid)
-	static const int fh = [] { const char *e = getenv("MC_SGM_UH"); return e ? atoi(e) : 0; }();
-	static const int fd = [] { const char *e = getenv("MC_SGM_UD"); return e ? atoi(e) : 0; }();
-	static const int fu = [] { const char *e = getenv("MC_SGM_UU"); return e ? atoi(e) : 0; }();
-	const int f = dirn <= 1 ? fh : dirn == 2 ? fd : fu;
-	return (f == 4 || f == 8 || f == 16) ? f : deflt;
-}
-
 template <int DIRN, int MODE, bool ARGMIN, bool DUAL>
 static void launch_pass(const SgmPassArgs &A, bool vec, hipStream_t st)
 {
@@ -354,7 +343,7 @@ static void launch_pass(const SgmPassArgs &A, bool vec, hipStream_t st)
 	// fewer waves than SIMDs (1024): nothing but prefetch depth hides HBM latency
 	// measured on MI355X (KITTI 370x1226x228): 4 steps ahead for the horizontal and the up sweep, 16 for the down sweep
 	// (three loads per step)
-	const int U = sgm_depth(DIRN, DIRN == 2 ? 16 : 4);
+	const int U = DIRN == 2 ? 16 : 4;
 #define MC_SGM_GO(VPL_, VEC_, U_) \
 	hipLaunchKernelGGL((sgm_pass_kernel<DIRN, VPL_, MODE, ARGMIN, VEC_, U_, DUAL>), grid, block, 0, st, A)
 	if (A.D <= 256) {

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) join_mfma_kernel(const float *__restrict_
 
 template <int KSTEPS, int SIDE>
 __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, const float *__restrict__ fR, float *__restrict__ vol,
-                                                 int C, int D, int ds, int H, int W, int y, int tile0, float *__restrict__ rings, int ablate)
+                                                 int C, int D, int ds, int H, int W, int y, int tile0, float *__restrict__ rings)
 {
 	// A wave owns TWO adjacent tiles (64 pixels) of one volume: both multiply against the same partner tile in the same
 	// step (with disparity offsets one tile apart), so every partner tile is fetched once per two tile products.
@@ -263,7 +263,7 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 		for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 		// partner tile entirely outside the image: nothing to multiply, the whole tile is NaN
 		const bool any_in = SIDE == 0 ? (p0 + 31 >= 0) : (p0 < W);
-		if (any_in && !(ablate & 4)) {
+		if (any_in) {
 #pragma unroll
 			for (int kk = 0; kk < KSTEPS; ++kk)
 				acc = SIDE == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(own[t][kk], part[kk], acc, 0, 0, 0)
@@ -272,9 +272,7 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 		const int jbit = (J & 1) << 5;
 		// interior tile: every d of it lies in [0, D) and every partner pixel inside the image
 		const bool interior = J >= 1 && 32 * J + 31 < D && (SIDE == 0 ? p0 >= 0 : p0 + 31 < W);
-		if (ablate & 2) {
-			if (acc[0] == 12345.0f) ring[wrow] = acc[3] + part[0];
-		} else if (interior) {
+		if (interior) {
 #pragma unroll
 			for (int i = 0; i < 16; ++i) {
 				const int mc = (i & 3) + 8 * (i >> 2);
@@ -290,7 +288,6 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 				if (d >= 0 && d < D) ring[wrow + (SIDE == 0 ? mc * 64 : 0) + (((wbase + mc) & 63) ^ jbit)] = pin ? acc[i] : NANV;
 			}
 		}
-		if (ablate & 1) return;
 		const bool last = J + 1 == nJ;
 #pragma unroll
 		for (int pass = 0; pass < 4; ++pass) {
@@ -329,7 +326,7 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 template <int KSTEPS>
 __global__ void __launch_bounds__(256) join_owner_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
                                                          float *__restrict__ volL, float *__restrict__ volR, int C, int D, int ds,
-                                                         int H, int W, int pairs_per_row, int ablate)
+                                                         int H, int W, int pairs_per_row)
 {
 	__shared__ __attribute__((aligned(16))) float rings[4][2 * 32 * 64];
 	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -340,8 +337,8 @@ __global__ void __launch_bounds__(256) join_owner_kernel(const float *__restrict
 	const int y = (k / blocks_per_row) * 8 + xcd;
 	const int w = (k % blocks_per_row) * 4 + wid;
 	if (y >= H || w >= 2 * pairs_per_row) return;
-	if (w < pairs_per_row) join_owner_tiles<KSTEPS, 0>(fL, fR, volL, C, D, ds, H, W, y, 2 * w, rings[wid], ablate);
-	else join_owner_tiles<KSTEPS, 1>(fL, fR, volR, C, D, ds, H, W, y, 2 * (w - pairs_per_row), rings[wid], ablate);
+	if (w < pairs_per_row) join_owner_tiles<KSTEPS, 0>(fL, fR, volL, C, D, ds, H, W, y, 2 * w, rings[wid]);
+	else join_owner_tiles<KSTEPS, 1>(fL, fR, volR, C, D, ds, H, W, y, 2 * (w - pairs_per_row), rings[wid]);
 }
 
 // fix_border (main.lua:922-927) on (H,W,ds): the n outermost pixels of one side replicate the
@@ -363,17 +360,15 @@ __global__ void __launch_bounds__(256) fix_border_hwd_kernel(float *__restrict__
 int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int ds, int H, int W, int n,
                     hipStream_t st)
 {
-	static const int env_join = [] { const char *e = getenv("MC_JOIN_KERNEL"); return e ? atoi(e) : 0; }();  // 1 = compute-once kernel
-	static const int env_abl = [] { const char *e = getenv("MC_JOIN_ABLATE"); return e ? atoi(e) : 0; }();
 	const int rows8 = (H + 7) / 8;
 	const int ks = (C + 1) / 2;
 	const dim3 block(256);
-	if (env_join != 1 && ds % 4 == 0 && (uintptr_t)volL % 16 == 0 && (uintptr_t)volR % 16 == 0 && ks <= 32) {
+	if (ds % 4 == 0 && (uintptr_t)volL % 16 == 0 && (uintptr_t)volR % 16 == 0 && ks <= 32) {
 		const int tiles_own = ((W + 31) / 32 + 1) / 2;   // pairs of 32-pixel tiles per image row and volume
 		const dim3 grid_o((unsigned)(rows8 * ((2 * tiles_own + 3) / 4) * 8));
-		if (ks <= 8) hipLaunchKernelGGL((join_owner_kernel<8>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own, env_abl);
-		else if (ks <= 16) hipLaunchKernelGGL((join_owner_kernel<16>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own, env_abl);
-		else hipLaunchKernelGGL((join_owner_kernel<32>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own, env_abl);
+		if (ks <= 8) hipLaunchKernelGGL((join_owner_kernel<8>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
+		else if (ks <= 16) hipLaunchKernelGGL((join_owner_kernel<16>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
+		else hipLaunchKernelGGL((join_owner_kernel<32>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
 		int rc = check_launch("stereo_join_hwd (owner tiles)");
 		if (rc || n <= 0) return rc;
 		hipLaunchKernelGGL(fix_border_hwd_kernel, dim3(cdiv((int64_t)H * n * 64, 256)), block, 0, st, volL, D, ds, H, W, n, -1);
@@ -399,49 +394,6 @@ int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, 
 	hipLaunchKernelGGL(fix_border_hwd_kernel, dim3(cdiv((int64_t)H * n * 64, 256)), block, 0, st, volR, D, ds, H, W, n, 1);
 	return check_launch("fix_border_hwd");
 }
-
-// ---- census, adcensus.cu:117-153 -----------------------------------------------------------------------
-__global__ void __launch_bounds__(256) census_kernel(const float *__restrict__ x0, const float *__restrict__ x1,
-                                                     float *__restrict__ out, int64_t size, int Cimg, int H, int W, int direction)
-{
-	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (id >= size) return;
-	int64_t t = id;
-	const int x = (int)(t % W);
-	t /= W;
-	const int y = (int)(t % H);
-	t /= H;
-	const int d = (int)t * direction;
-	float dist;
-	if (0 <= x + d && x + d < W) {
-		dist = 0;
-		for (int i = 0; i < Cimg; i++) {
-			const int ind_p = (i * H + y) * W + x;
-			for (int yy = y - 4; yy <= y + 4; yy++) {
-				for (int xx = x - 4; xx <= x + 4; xx++) {
-					if (0 <= xx && xx < W && 0 <= xx + d && xx + d < W && 0 <= yy && yy < H) {
-						const int ind_q = (i * H + yy) * W + xx;
-						if ((x0[ind_q] < x0[ind_p]) != (x1[ind_q + d] < x1[ind_p + d])) dist++;
-					} else {
-						dist++;
-					}
-				}
-			}
-		}
-		dist /= Cimg;
-	} else {
-		dist = __builtin_nanf("");
-	}
-	out[id] = dist;
-}
-
-int census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, hipStream_t st)
-{
-	const int64_t size = (int64_t)D * H * W;
-	hipLaunchKernelGGL(census_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, x0, x1, vol, size, Cimg, H, W, direction);
-	return check_launch("census");
-}
-
 
 // ---- census, signature form ---------------------------------------------------------------------
 // The 81 comparisons x[q] < x[p] of a pixel's 9x9 window do not depend on the disparity: census_sig_kernel packs them

@@ -25,7 +25,6 @@ const char *mc_last_error(void);
 int mc_fill_nan(float *p, int64_t n, void *stream);
 int mc_stereo_join(const float *featL, const float *featR, float *volL, float *volR, int C, int D, int H, int W, void *stream);
 int mc_ad(const float *x0, const float *x1, float *vol, int D, int H, int W, int direction, void *stream);
-int mc_census(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction, void *stream);
 size_t mc_census_scratch_bytes(int Cimg, int H, int W);
 int mc_census_ws(const float *x0, const float *x1, float *vol, int Cimg, int D, int H, int W, int direction,
                  void *scratch, size_t scratch_bytes, void *stream);
@@ -51,10 +50,40 @@ int mc_subpixel_enchancement(const float *d0, const float *vol, float *out, int 
 int mc_median2d(const float *img, float *out, int H, int W, int kernel_size, void *stream);
 int mc_mean2d(const float *img, const float *kernel, float *out, int H, int W, int ks, float alpha2, void *stream);
 int mc_normalize_forward(const float *in, float *norm, float *out, int N, int C, int H, int W, void *stream);
+typedef struct mc_params {
+	int L1;
+	float tau1;
+	int cbca_i1;
+	int cbca_i2;
+	float pi1;
+	float pi2;
+	int sgm_i;
+	float sgm_q1;
+	float sgm_q2;
+	float alpha1;
+	float tau_so;
+	double blur_sigma;
+	float blur_t;
+	int lr_check;
+	int border_n;
+	int median_k;
+	int sm_terminate;
+	int sm_skip;
+	int left_only;
+} mc_params;
+size_t mc_predict_workspace_bytes(const mc_params *p, int C, int D, int H, int W);
+int mc_predict(const mc_params *p, const float *x0, const float *x1,
+               const float *featL, const float *featR, int C,
+               const float *rawL, const float *rawR, int D, int H, int W,
+               void *workspace, size_t workspace_bytes,
+               float *volL_out, float *volR_out, float *dispL0_out, float *dispR0_out,
+               float *disp_out, void *stream);
 ]]
 
 local lib = ffi.load('mcadcensus')
-assert(lib.mc_version() == 1, 'libmcadcensus ABI version mismatch')
+local MC_ABI_VERSION = 3   -- include/mc_adcensus.h; tests/test_lua_shim.py checks this constant and every prototype above
+assert(lib.mc_version() == MC_ABI_VERSION, ('libmcadcensus ABI version %d, this shim is written for %d'):format(
+   lib.mc_version(), MC_ABI_VERSION))
 
 local function check(rc, what)
    if rc ~= 0 then
@@ -198,6 +227,53 @@ function adcensus.Normalize_forward(input, norm, output)     -- adcensus.cu:1310
    check(lib.mc_normalize_forward(ptr(input, 'Normalize_forward'), ptr(norm, 'Normalize_forward'),
                                   ptr(output, 'Normalize_forward'), input:size(1), input:size(2), input:size(3),
                                   input:size(4), nil), 'Normalize_forward')
+end
+
+-- NEW entry (no counterpart in libadcensus): the whole of stereo_predict (main.lua:929-1082) from the cost-volume stage
+-- on in ONE call (mc_predict): NaN fill, StereoJoin, fix_border, cross, cbca, sgm2, both arg-mins, the LR check,
+-- interpolation, sub-pixel, median and the range-gated Gaussian -- what main.lua does in ~25 adcensus.* / cutorch calls.
+--   o        the option table of main.lua (opt.L1, opt.tau1, opt.cbca_i1, ... opt.sm_terminate, opt.sm_skip)
+--   dataset  'kitti' | 'kitti2015' | 'mb'  (selects the LR-check branch, main.lua:1054)
+--   x_batch  (2,1,H,W) CudaTensor, the normalised pair
+--   input    arch fast: net_te.output (2,C,H,W) after forward_free; any other arch: the raw volumes (2,disp_max,H,W)
+--            (adcensus.ad / census / fc_stack output, NaN outside the valid range)
+--   border_n (get_window_size(net_te) - 1) / 2 for arch fast (fix_border, main.lua:922-927); ignored otherwise
+--   both     true for `-a predict` (both directions; returns the left.bin / right.bin volumes), false otherwise
+-- Returns disp (1,1,H,W) and, when `both`, volL, volR (1,disp_max,H,W).
+local SM_TERMINATE = {[''] = 0, cnn = 1, cbca1 = 2, sgm = 3, cbca2 = 4, occlusion = 5, mismatch = 6,
+                      subpixel_enchancement = 7, median = 8, bilateral = 9}
+local SM_SKIP = {[''] = 0, cbca = 1, sgm = 2, occlusion = 3, subpixel_enchancement = 4, median = 5, bilateral = 6}
+local predict_ws = torch.CudaTensor()
+function adcensus.predict(o, dataset, arch, x_batch, input, disp_max, border_n, both)
+   local p = ffi.new('mc_params')
+   p.L1, p.tau1, p.cbca_i1, p.cbca_i2 = o.L1, o.tau1, o.cbca_i1, o.cbca_i2
+   p.pi1, p.pi2, p.sgm_i, p.sgm_q1, p.sgm_q2 = o.pi1, o.pi2, o.sgm_i, o.sgm_q1, o.sgm_q2
+   p.alpha1, p.tau_so, p.blur_sigma, p.blur_t = o.alpha1, o.tau_so, o.blur_sigma, o.blur_t
+   p.lr_check = (dataset == 'kitti' or dataset == 'kitti2015') and 1 or 0
+   p.border_n = arch == 'fast' and border_n or 0
+   p.median_k = 5
+   p.sm_terminate = SM_TERMINATE[o.sm_terminate or ''] or error('unknown -sm_terminate ' .. tostring(o.sm_terminate))
+   p.sm_skip = SM_SKIP[o.sm_skip or ''] or error('unknown -sm_skip ' .. tostring(o.sm_skip))
+   p.left_only = both and 0 or 1
+   local H, W = x_batch:size(3), x_batch:size(4)
+   local C = arch == 'fast' and input:size(2) or 0
+   local need = tonumber(lib.mc_predict_workspace_bytes(p, C, disp_max, H, W))
+   if need == 0 then error('mc_predict_workspace_bytes: bad arguments', 2) end
+   if predict_ws:nElement() * 4 < need + 256 then predict_ws:resize(math.ceil((need + 256) / 4)) end
+   local ws = ffi.cast('char *', predict_ws:data())
+   ws = ws + (256 - tonumber(ffi.cast('uintptr_t', ws)) % 256) % 256      -- mc_predict wants a 256-byte aligned workspace
+   local disp = torch.CudaTensor(1, 1, H, W)
+   local volL, volR, pl, pr = nil, nil, nil, nil
+   if both then
+      volL, volR = torch.CudaTensor(1, disp_max, H, W), torch.CudaTensor(1, disp_max, H, W)
+      pl, pr = volL:data(), volR:data()
+   end
+   local x0, x1 = x_batch[1]:data(), x_batch[2]:data()
+   ptr(x_batch, 'predict'); ptr(input, 'predict')
+   local fl, fr, rl, rr = nil, nil, nil, nil
+   if arch == 'fast' then fl, fr = input[1]:data(), input[2]:data() else rl, rr = input[1]:data(), input[2]:data() end
+   check(lib.mc_predict(p, x0, x1, fl, fr, C, rl, rr, disp_max, H, W, ws, need, pl, pr, nil, nil, disp:data(), nil), 'predict')
+   return disp, volL, volR
 end
 
 function adcensus.version()                                  -- adcensus.cu:2055-2059

@@ -24,7 +24,7 @@ import time
 import numpy as np
 
 from .binio import write_bin
-from .params import NET_SHAPES, TABLES
+from .params import NET_SHAPES, SM_SKIP, SM_TERMINATE, TABLES
 
 
 def rgb2y(img):
@@ -45,8 +45,9 @@ def load_image(path):
 
 def normalize(x):
     """x:add(-x:mean()):div(x:std()) -- torch's unbiased std, accumulations in double (main.lua:1095-1096)."""
-    xd = x.astype(np.float64)
-    return ((x - np.float32(xd.mean())) / np.float32(xd.std(ddof=1))).astype(np.float32)
+    # in the reference's order: the mean is subtracted in float32 first, then the std of THAT tensor divides it
+    y = (x - np.float32(x.astype(np.float64).mean())).astype(np.float32)
+    return (y / np.float32(y.astype(np.float64).std(ddof=1))).astype(np.float32)
 
 
 def parse(argv):
@@ -66,8 +67,11 @@ def parse(argv):
         ap.add_argument("-" + k, type=int, default=t[k])
     for k in ("tau1", "pi1", "pi2", "sgm_q1", "sgm_q2", "alpha1", "tau_so", "blur_sigma", "blur_t"):
         ap.add_argument("-" + k, type=float, default=t[k])
+    ap.add_argument("-sm_terminate", default="", choices=sorted(SM_TERMINATE), help="main.lua:25")
+    ap.add_argument("-sm_skip", default="", choices=sorted(SM_SKIP), help="main.lua:26")
     opt = ap.parse_args(argv[2:])
     prm = dict(t)
+    prm["sm_terminate"], prm["sm_skip"] = opt.sm_terminate, opt.sm_skip   # make_params maps the stage names
     for k in ("L1", "cbca_i1", "cbca_i2", "sgm_i", "tau1", "pi1", "pi2", "sgm_q1", "sgm_q2", "alpha1", "tau_so", "blur_sigma",
               "blur_t"):
         prm[k] = getattr(opt, k)
@@ -194,6 +198,7 @@ def main(argv=None):
         raw = raw_volumes_slow(features_slow(x_batch, layers), fc_layers, D, prm["border_n"])
         return stereo_predict_fused(x_batch, prm, D, raw=raw, workspace=workspace, want_volumes=want_volumes)
     if opt.a == "time":  # main.lua:1140-1167
+        prm["left_only"] = 1  # outside `-a predict` dataset mb runs direction -1 only (mb_directions, main.lua:953-955)
         H, W, D = (240, 320, 32) if opt.tiny else ((350, 1242, 228) if dataset != "mb" else (1000, 1500, 200))
         x_batch = torch.empty((2, 1, H, W), dtype=torch.float32, device=dev).normal_()
         ws = Workspace(prm, D, H, W, dev)

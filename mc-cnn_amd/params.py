@@ -53,7 +53,7 @@ class McParams(C.Structure):
         ("sgm_q1", C.c_float), ("sgm_q2", C.c_float), ("alpha1", C.c_float), ("tau_so", C.c_float),
         ("blur_sigma", C.c_double), ("blur_t", C.c_float),
         ("lr_check", C.c_int), ("border_n", C.c_int), ("median_k", C.c_int),
-        ("sm_terminate", C.c_int), ("sm_skip", C.c_int),
+        ("sm_terminate", C.c_int), ("sm_skip", C.c_int), ("left_only", C.c_int),
     ]
 
 
@@ -64,7 +64,7 @@ def make_params(d):
         d = PRESETS[d]
     p = McParams()
     for k, _ in McParams._fields_:
-        v = d.get(k, 0) if k in ("sm_terminate", "sm_skip") else d[k]
+        v = d.get(k, 0) if k in ("sm_terminate", "sm_skip", "left_only") else d[k]
         if k == "sm_terminate" and isinstance(v, str):
             v = SM_TERMINATE[v]
         if k == "sm_skip" and isinstance(v, str):

@@ -3,5 +3,5 @@
 TAG=$1; CFG=$2; STEPS=${3:-10}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$CFG -o $CFG -- python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-ref-gpu > $O/prof_$CFG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$CFG -o $CFG -- python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-ref-gpu --no-north-star --no-ops > $O/prof_$CFG.log 2>&1
 cd $GRAFT_REPO_ROOT && python scripts/rocpd_summary.py $O/prof_$CFG/${CFG}_results.db > $O/${CFG}_kernel_stats.csv && cut -d, -f1-4,7,8 $O/${CFG}_kernel_stats.csv | head -12

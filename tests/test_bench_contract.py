@@ -39,3 +39,26 @@ def test_workloads_are_baseline_configs():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'default="kitti_fast"' in src          # BASELINE configs[1] is what `python bench.py` measures
     assert base["metric"].startswith("Mega-pixel-disparities/sec")
+
+
+def test_dominant_kernel_is_picked_by_time_not_bytes():
+    """for kitti_slow the byte model is largest for SGM while CBCA takes the most time."""
+    b = _bench()
+    import mc_cnn_amd as mc
+    prm = dict(mc.PRESETS["kitti_slow"])
+    ab = b.algorithmic_bytes(prm, 370, 1226, 228, 0)
+    assert ab["sgm"] > ab["cbca"]
+    assert b.pick_dominant({"cbca": 2.8, "sgm": 2.0, "join": 0.0}, ab) == "cbca"
+    assert b.pick_dominant({"cbca": 0.5, "sgm": 2.0}, ab) == "sgm"
+    rec = b.roofline_record("kitti_slow", prm, 370, 1226, 228, 0, {"cbca": 2.8, "sgm": 2.0}, 6.0)
+    assert rec["kernel"].startswith("cbca_strip") and set(rec["kernels"]) == {"cbca", "sgm"}
+    assert abs(rec["kernels"]["sgm"]["frac"] - ab["sgm"] / 2.0e-3 / 1e9 / 8000.0) < 1e-3
+    assert b.launches_per_step(dict(mc.PRESETS["mb_slow"]), 0) == {"join": 0, "cbca": 36, "sgm": 3}
+
+
+def test_gpus_n_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus N` must not exit 2 when WORLD_SIZE is unset: it starts the ranks itself."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if args.gpus > 1 and "WORLD_SIZE" not in os.environ:' in src and "spawn_ranks(args.gpus)" in src
+    assert "ranks_seen" in src and "gathered_equals_single_gpu" in src
+    assert '"verify": verify' in src and '"north_star": north' in src

@@ -39,6 +39,42 @@ def test_fc_stack(mc, oracle, C, H, W, D, n_hidden):
         assert want[ok].std() > 1e-3, want[ok].std()  # the comparison is not vacuous (outputs are not saturated)
 
 
+@pytest.mark.parametrize("C,H,W,D,n_hidden", [(112, 3, 300, 20, 3), (32, 4, 250, 9, 2)])
+def test_fc_stack_vs_torch_addmm_chain(mc, C, H, W, D, n_hidden):
+    """Second, independent reference: what the reference's own modules do (SpatialConvolution1_fw.lua:11-31: `addmm` of the
+    (out,in) weight with the (in, pixels) activations + bias, nn.ReLU between, nn.Sigmoid at the end; main.lua:958-983
+    builds the input by concatenating featL[:,y,x] and featR[:,y,x-d]) as a plain fp32 torch addmm chain per disparity.
+    Widths straddle several 96-voxel tiles of the MFMA kernel.  Tolerance 1e-4: BLAS summation order is third-party."""
+    from util import features
+    from mc_cnn_amd.fc import fc_cost_volumes
+    torch.backends.cuda.matmul.allow_tf32 = False
+    f = np.maximum(features(C, H, W, seed=C + W), 0) * 3.0
+    layers = make_layers(C, n_hidden, seed=W + 1)
+    ft = torch.from_numpy(f).cuda()
+    dl = [(torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda()) for w, b in layers]
+    vl, vr = fc_cost_volumes(ft, dl, D)
+    want_l = torch.full((D, H, W), float("nan"), device="cuda")
+    want_r = torch.full((D, H, W), float("nan"), device="cuda")
+    for d in range(D):
+        n = W - d
+        if n <= 0:
+            break
+        x = torch.cat([ft[0][:, :, d:], ft[1][:, :, :n]], 0).reshape(2 * C, H * n)      # (in, pixels), main.lua:968-972
+        for li, (w, b) in enumerate(dl):
+            x = torch.addmm(b[:, None], w, x)                                               # SpatialConvolution1_fw.lua:21
+            x = torch.relu(x) if li < len(dl) - 1 else torch.sigmoid(x)
+        s = x.reshape(H, n)
+        want_l[d, :, d:] = s
+        want_r[d, :, :n] = s
+    torch.cuda.synchronize()
+    for got, want, name in ((vl[0], want_l, "left"), (vr[0], want_r, "right")):
+        assert torch.equal(torch.isnan(got), torch.isnan(want)), "%s: NaN mask differs" % name
+        ok = ~torch.isnan(want)
+        err = float((got[ok] - want[ok]).abs().max())
+        assert err <= 1e-4, "%s: max |diff| = %g" % (name, err)
+        assert float(want[ok].std()) > 1e-3
+
+
 def test_main_predict_arch_slow(mc, oracle, tmp_path, monkeypatch):
     """`main.py kitti slow -a predict ...`: conv features -> FC stack -> fix_border -> stereo_predict.  The FC stack is
     held to 1e-4; everything after it is bit-exact given the same raw volumes, which is what is checked here: the

@@ -1,0 +1,95 @@
+"""-m gpu: the kernel instantiations that only the benchmarked SIZES select, forced at small shapes through the
+test hooks of the C ABI (mc_cbca_ws_cfg, mc_transpose_cfg) and compared with the oracle:
+
+  * rows per CBCA strip rb in {16, 25, 40} (KITTI size runs 25, 1000x1500 runs 40; small shapes pick 16),
+  * the non-temporal instantiations of the CBCA strip kernel and of the layout transposes (selected above 768 MB),
+  * plane sub-ranges of a volume,
+  * the three-operation division by 9 of the register-window kernels against the IEEE quotient, exhaustively.
+(tests/test_gpu_fullsize.py checks the same code at the real sizes against the reference's kernels.)"""
+import numpy as np
+import pytest
+
+from util import blocky_pair, diff_report, random_pair, raw_volumes, same_bits, smooth_pair
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+@pytest.mark.parametrize("H,W,D", [(90, 300, 9), (41, 519, 6), (27, 253, 5), (83, 64, 12)])
+@pytest.mark.parametrize("rb", [16, 25, 40])
+@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.02), ("random", 5, 0.13), ("blocky", 14, 0.2)])
+def test_cbca_forced_rows_and_cache_policy(mc, oracle, H, W, D, rb, nt, mk, L1, tau1):
+    x0, x1 = {"smooth": lambda: smooth_pair(H, W, 8, seed=H), "random": lambda: random_pair(H, W, seed=W),
+              "blocky": lambda: blocky_pair(H, W, seed=D)}[mk]()
+    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
+    vl, vr = raw_volumes(D, H, W, seed=13)
+    for direction, vol in ((-1, vl), (1, vr)):
+        want = oracle.cbca(x0c, x1c, vol, direction)
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=nt)
+        got = out.cpu().numpy()
+        assert same_bits(got, want), diff_report(got, want, "cbca rb=%d nt=%d dir=%d" % (rb, nt, direction))
+
+
+def test_cbca_plane_range(mc, oracle):
+    H, W, D = 30, 100, 11
+    x0, x1 = smooth_pair(H, W, 8, seed=4)
+    x0c, x1c = oracle.cross(x0, 14, 0.05), oracle.cross(x1, 14, 0.05)
+    vl, _ = raw_volumes(D, H, W, seed=2)
+    want = oracle.cbca(x0c, x1c, vl, -1)
+    out = torch.full((1, D, H, W), -7.0, device="cuda")
+    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, d0=3, nd=5)
+    got = out.cpu().numpy()[0]
+    assert same_bits(got[3:8], want[3:8]), diff_report(got[3:8], want[3:8], "planes 3..7")
+    assert (got[:3] == -7.0).all() and (got[8:] == -7.0).all(), "planes outside [d0, d0+nd) were written"
+
+
+@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("R,Cn", [(228, 370 * 7), (65, 129), (256, 1000)])
+def test_transposes_forced_cache_policy(mc, R, Cn, nt):
+    rng = np.random.default_rng(R)
+    a = rng.standard_normal((R, Cn)).astype(np.float32)
+    a[0, :5] = np.nan
+    out = torch.empty((Cn, R), device="cuda")
+    mc.adcensus.transpose_cfg(dev(a), out, R, Cn, Cn, R, scale=0.25, nt=nt)
+    assert same_bits(out.cpu().numpy(), (a * np.float32(0.25)).T)
+
+
+def test_division_by_nine_is_the_ieee_quotient_for_every_float(mc):
+    """all 2^32 bit patterns: inside the guarded range the packed q = s*r, e = fma(-9,q,s), q' = fma(e,r,q) form must
+    equal s / 9.0f; outside it the kernels take the IEEE divide (and the count there shows the guard is needed)."""
+    bad_in = bad_out = 0
+    for first in range(0, 1 << 32, 1 << 30):
+        i, o, ex = mc.adcensus.selftest_div9(first, 1 << 30)
+        assert i == 0, "mismatch inside the guarded range, e.g. bits 0x%08x" % ex
+        bad_in += i
+        bad_out += o
+    assert bad_in == 0
+    assert bad_out > 0   # inf / huge / tiny inputs do differ: the guard is not decorative
+
+
+def test_left_only_skips_the_right_volume_without_changing_the_left(mc):
+    """mc_params.left_only: dataset mb outside `-a predict` runs direction -1 only (main.lua:953-955); disp is the same"""
+    H, W, D = 40, 120, 24
+    prm = dict(mc.PRESETS["mb_slow"], cbca_i2=3)
+    x0, x1 = smooth_pair(H, W, 10, seed=9)
+    xb = dev(np.stack([x0, x1]))[:, None]
+    vl, vr = raw_volumes(D, H, W, seed=5)
+    raw = (dev(vl), dev(vr))
+    both = mc.stereo_predict_fused(xb, prm, D, raw=raw)["disp"].cpu().numpy()
+    left = mc.stereo_predict_fused(xb, dict(prm, left_only=1), D, raw=raw)["disp"].cpu().numpy()
+    assert same_bits(left, both)
+    # a right-side output asked for: both directions run regardless
+    r = mc.stereo_predict_fused(xb, dict(prm, left_only=1), D, raw=raw, want_disp0=True)
+    w = mc.stereo_predict_fused(xb, prm, D, raw=raw, want_disp0=True)
+    assert same_bits(r["dispR0"].cpu().numpy(), w["dispR0"].cpu().numpy())
+    # kitti (LR check): the flag is ignored
+    prk = dict(mc.PRESETS["kitti_slow"])
+    a = mc.stereo_predict_fused(xb, prk, D, raw=raw)["disp"].cpu().numpy()
+    b = mc.stereo_predict_fused(xb, dict(prk, left_only=1), D, raw=raw)["disp"].cpu().numpy()
+    assert same_bits(a, b)

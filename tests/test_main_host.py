@@ -26,6 +26,24 @@ def test_flags_override_defaults_and_stage_names():
     assert (p.sm_terminate, p.sm_skip) == (3, 5)
 
 
+def test_stage_switch_flags_reach_mc_params():
+    """-sm_terminate / -sm_skip (main.lua:25-26) are CLI flags of the Python host too and land in mc_params"""
+    _, _, opt, prm = mcmain.parse(["kitti", "slow", "-a", "predict", "-sm_terminate", "cbca1", "-sm_skip", "sgm"])
+    p = params.make_params(prm)
+    assert (p.sm_terminate, p.sm_skip, p.left_only) == (params.SM_TERMINATE["cbca1"], params.SM_SKIP["sgm"], 0)
+    _, _, _, prm = mcmain.parse(["mb", "fast", "-a", "predict"])
+    assert params.make_params(prm).sm_terminate == 0 and params.make_params(dict(prm, left_only=1)).left_only == 1
+
+
+def test_normalize_follows_the_reference_order():
+    """main.lua:1095: x:add(-x:mean()):div(x:std()) -- the std is taken AFTER the float32 mean subtraction"""
+    rng = np.random.default_rng(3)
+    x = (rng.random((1, 37, 41)) * 255).astype(np.float32)
+    y = (x - np.float32(x.astype(np.float64).mean())).astype(np.float32)
+    want = y / np.float32(y.astype(np.float64).std(ddof=1))
+    assert np.array_equal(mcmain.normalize(x), want)
+
+
 def test_normalize_is_torch_unbiased_std():
     rng = np.random.default_rng(0)
     x = (rng.random((1, 7, 9)) * 255).astype(np.float32)
