@@ -67,7 +67,7 @@ def _load():
         "mc_predict": [C.POINTER(McParams), vp, vp, vp, vp, i, vp, vp, i, i, i, vp, sz, vp, vp, vp, vp, vp, vp],
         "mc_predict_timed": [C.POINTER(McParams), vp, vp, vp, vp, i, vp, vp, i, i, i, vp, sz, vp, vp,
                              C.POINTER(C.c_float)],
-        "mc_cbca_ws_cfg": [vp, vp, vp, vp, i, i, i, i, vp, sz, i, i, i, i, vp],
+        "mc_cbca_ws_cfg": [vp, vp, vp, vp, i, i, i, i, vp, sz, i, i, i, i, i, vp],
         "mc_transpose_cfg": [vp, vp, i64, i64, i64, i64, f, i, vp],
         "mc_selftest_div9": [C.c_uint32, C.c_uint64, vp, vp],
     }
