@@ -251,21 +251,14 @@ int mc_predict_timed(const mc_params *p, const float *x0, const float *x1,
 
 /* mc_cbca_ws with the launch geometry forced instead of derived from the problem size: rows per strip `rb` (0 = auto),
  * cache policy `nt` (-1 = auto, 0 = default policy, 1 = non-temporal volume accesses), planes [d0, d0+nd) only
- * (nd = 0: all); fused = 1: TWO iterations in one launch, vol_out = cbca(cbca(vol_in)) (the kernel mc_predict uses for
- * pairs of iterations).  Lets small-shape parity tests reach the instantiations the benchmarked sizes select. */
+ * (nd = 0: all).  Lets small-shape parity tests reach the instantiations the benchmarked sizes select. */
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
                    int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
-                   int rb, int nt, int d0, int nd, int fused, void *stream);
+                   int rb, int nt, int d0, int nd, void *stream);
 
 /* (H,W,D)<->(D,H,W) transpose with the cache policy forced (nt as above); scale multiplies every element. */
 int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, int64_t ldin, int64_t ldout,
                      float scale, int nt, void *stream);
-
-/* Walks `count` consecutive float bit patterns from `first` on the device and compares the three-operation division
- * by 9 used by the cbca kernels with the IEEE quotient.  counters (DEVICE, 3 x uint64, zeroed by the caller):
- * [0] mismatches inside the guarded magnitude range (must stay 0), [1] mismatches outside it (handled by the IEEE
- * divide at run time), [2] one offending bit pattern. */
-int mc_selftest_div9(uint32_t first, uint64_t count, unsigned long long *counters, void *stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

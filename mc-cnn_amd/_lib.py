@@ -16,7 +16,7 @@ SYMBOLS = [
     "mc_argmin", "mc_spatial_argmin", "mc_outlier_detection", "mc_interpolate_occlusion",
     "mc_interpolate_mismatch", "mc_subpixel_enchancement", "mc_median2d", "mc_mean2d", "mc_gaussian_host",
     "mc_normalize_forward", "mc_predict_workspace_bytes", "mc_predict", "mc_predict_timed",
-    "mc_cbca_ws_cfg", "mc_transpose_cfg", "mc_selftest_div9",
+    "mc_cbca_ws_cfg", "mc_transpose_cfg",
 ]
 
 
@@ -67,9 +67,8 @@ def _load():
         "mc_predict": [C.POINTER(McParams), vp, vp, vp, vp, i, vp, vp, i, i, i, vp, sz, vp, vp, vp, vp, vp, vp],
         "mc_predict_timed": [C.POINTER(McParams), vp, vp, vp, vp, i, vp, vp, i, i, i, vp, sz, vp, vp,
                              C.POINTER(C.c_float)],
-        "mc_cbca_ws_cfg": [vp, vp, vp, vp, i, i, i, i, vp, sz, i, i, i, i, i, vp],
+        "mc_cbca_ws_cfg": [vp, vp, vp, vp, i, i, i, i, vp, sz, i, i, i, i, vp],
         "mc_transpose_cfg": [vp, vp, i64, i64, i64, i64, f, i, vp],
-        "mc_selftest_div9": [C.c_uint32, C.c_uint64, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

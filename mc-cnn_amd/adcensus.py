@@ -85,7 +85,7 @@ def cbca(x0c, x1c, vol_in, vol_out, direction):
                          _stream()), "cbca")
 
 
-def cbca_cfg(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, d0=0, nd=0, fused=0):
+def cbca_cfg(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, d0=0, nd=0):
     """Test / bench hook (mc_cbca_ws_cfg): adcensus.cbca with the strip kernel's launch geometry forced -- rows per
     strip, non-temporal instantiation, plane range -- instead of derived from the problem size."""
     _chk(x0c, x1c, vol_in, vol_out)
@@ -93,7 +93,7 @@ def cbca_cfg(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, d0=0, nd=0, fuse
     need = lib.mc_cbca_scratch_bytes(H, W)
     scratch = _scratch_for(vol_out.device, need)
     check(lib.mc_cbca_ws_cfg(_p(x0c), _p(x1c), _p(vol_in), _p(vol_out), D, H, W, int(direction), scratch.data_ptr(), need,
-                             int(rb), int(nt), int(d0), int(nd), int(fused), _stream()), "cbca_cfg")
+                             int(rb), int(nt), int(d0), int(nd), _stream()), "cbca_cfg")
 
 
 def transpose_cfg(inp, out, rows, cols, ldin, ldout, scale=1.0, nt=-1):
@@ -101,14 +101,6 @@ def transpose_cfg(inp, out, rows, cols, ldin, ldout, scale=1.0, nt=-1):
     _chk(inp, out)
     check(lib.mc_transpose_cfg(_p(inp), _p(out), int(rows), int(cols), int(ldin), int(ldout), float(scale), int(nt),
                                _stream()), "transpose_cfg")
-
-
-def selftest_div9(first, count):
-    """Test hook (mc_selftest_div9): (mismatches inside the guarded range, outside it, one offending bit pattern)."""
-    c = torch.zeros(3, dtype=torch.int64, device="cuda")
-    check(lib.mc_selftest_div9(int(first), int(count), c.data_ptr(), _stream()), "selftest_div9")
-    v = c.cpu().tolist()
-    return v[0], v[1], v[2] & 0xFFFFFFFF
 
 
 def cbca_reference_shaped(x0c, x1c, vol_in, vol_out, direction):

@@ -39,11 +39,6 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
                      int direction, hipStream_t st);
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
-int cbca_fused2(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
-                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
-int cbca_lean(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
-              hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
-int div9_selftest(uint32_t first, uint64_t count, unsigned long long *counters, hipStream_t st);
 size_t fc_workspace_bytes(int C, int n_hidden, int H, int W);
 int fc_stack(const float *featL, const float *featR, int C, int H, int W, int D, const float *const *weights,
              const float *const *biases, int n_layers, float *volL, float *volR, void *workspace, hipStream_t st);
@@ -528,7 +523,7 @@ int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *v
 }
 
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
-                   void *scratch, size_t scratch_bytes, int rb, int nt, int d0, int nd, int fused, void *stream)
+                   void *scratch, size_t scratch_bytes, int rb, int nt, int d0, int nd, void *stream)
 {
 	MC_REQUIRE(x0c && x1c && vol_in && vol_out && scratch, "mc_cbca_ws_cfg: null pointer");
 	MC_REQUIRE(vol_in != vol_out, "mc_cbca_ws_cfg: in-place aggregation is not supported");
@@ -538,15 +533,13 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
 	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws_cfg: image too large for 32-bit plane offsets");
-	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && fused >= 0 && fused <= 7, "mc_cbca_ws_cfg: bad rb / nt / fused");
+	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1, "mc_cbca_ws_cfg: bad rb / nt");
 	MC_REQUIRE(d0 >= 0 && nd >= 0 && d0 + nd <= D, "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
 	CbcaCfg cfg;
-	cfg.rb = rb; cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd; cfg.fused = fused;
-	if (fused == 2) return cbca_lean(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg);   // (no overflow path: arms <= 254)
-	if (fused) return cbca_fused2(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg);
+	cfg.rb = rb; cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd;
 	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg);
 	if (rc) return rc;
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
@@ -561,11 +554,6 @@ int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, in
 	return transpose(in, out, rows, cols, ldin, ldout, scale_, as_stream(stream), nt);
 }
 
-int mc_selftest_div9(uint32_t first, uint64_t count, unsigned long long *counters, void *stream)
-{
-	MC_REQUIRE(counters && count >= 1 && count <= ((uint64_t)1 << 32), "mc_selftest_div9: bad arguments");
-	return div9_selftest(first, count, counters, as_stream(stream));
-}
 
 size_t mc_sgm2_tmp_bytes(int H, int W, int D)
 {

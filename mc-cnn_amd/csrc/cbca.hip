@@ -368,292 +368,6 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 }
 
 
-// =====================================================================================================
-// cbca: wave-autonomous strips, register-window form
-// =====================================================================================================
-// Same decomposition as above (one wave = one disparity plane x a strip of 256 staged columns x RB output rows, walked
-// top to bottom, no block barrier), but the minimal 3x3 support -- the common case on textured images -- never touches
-// LDS: a lane keeps its own four columns of the last three rows in REGISTERS as the five horizontally adjacent column
-// pairs (-1,0) (0,1) (1,2) (2,3) (3,4) (the outer two columns come from the neighbour lanes by DPP wave shifts), so the
-// nine additions of two neighbouring outputs are nine packed v_pk_add_f32 on naturally aligned register pairs, in the
-// reference's order (rows ascending, x ascending, one accumulator per output, adcensus.cu:356-373).  The division by the
-// count 9 is three packed operations (q = s*r, e = fma(-9,q,s), q' = fma(e,r,q): correctly rounded for every s in the
-// guarded range, checked exhaustively by mc_selftest_div9; anything outside the range takes the IEEE divide).  The
-// "support is minimal" tests are per-lane booleans, i.e. lane masks in SGPRs combined by scalar instructions.  The frame
-// has a halo of 4 columns on each side (lanes 0 and 63 only feed their neighbours), so row loads and result stores are
-// the lane's own dwordx4.  Rows and byte-wise minimum arm lengths still go to the wave's LDS ring: outputs with a larger
-// support are compacted and summed from there exactly as before (window form, then the row-by-row loop).
-constexpr int C2_STEP = 248;   // output columns per strip (frame columns 4 .. 251)
-constexpr int C2_HALO = 4;
-
-__global__ void __launch_bounds__(256) div9_selftest_kernel(uint32_t first, uint64_t count, unsigned long long *__restrict__ bad_in,
-                                                            unsigned long long *__restrict__ bad_out, uint32_t *__restrict__ example)
-{
-	// every bit pattern first .. first+count-1: inside the guarded range the packed form must equal IEEE s / 9
-	unsigned long long nin = 0, nout = 0;
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t bits = first + (uint32_t)i;
-		const float s = __uint_as_float(bits);
-		const cb_f2 q = div9_pk(cb_f2{s, -s});
-		const float want = s / 9.0f;
-		const bool same = (__float_as_uint(q.x) == __float_as_uint(want) || (want != want && q.x != q.x)) &&
-		                  (__float_as_uint(q.y) == __float_as_uint(-want) || (want != want && q.y != q.y));
-		if (!same) {
-			if (div9_in_range(s)) { ++nin; *example = bits; }
-			else ++nout;
-		}
-	}
-	if (nin) atomicAdd(bad_in, nin);
-	if (nout) atomicAdd(bad_out, nout);
-}
-
-int div9_selftest(uint32_t first, uint64_t count, unsigned long long *counters, hipStream_t st)
-{
-	hipLaunchKernelGGL(div9_selftest_kernel, dim3(4096), dim3(256), 0, st, first, count, counters, counters + 1, (uint32_t *)(counters + 2));
-	return check_launch("div9_selftest");
-}
-
-template <int CS_RING, int CS_LA, int CS_WR, bool NT>
-__global__ void __launch_bounds__(256) cbca_strip2_kernel(const CbcaArgs A)
-{
-	constexpr int PF = 3;                      // rows in flight = rows of the register window: the loop is unrolled by 3
-	constexpr int CS_UP = CS_LA;
-	constexpr int VOL_AUX = NT ? 2 : 0;
-	auto slot = [](int r) { return (CS_RING & (CS_RING - 1)) == 0 ? (r & (CS_RING - 1)) : (int)((unsigned)(r + 4 * CS_RING) % (unsigned)CS_RING); };
-	__shared__ float Vring[4][CS_RING * CS_COLS];
-	__shared__ cb_u32 Mring[4][CS_RING * CS_COLS];
-	__shared__ float Rrow[4][CS_COLS];          // results of the current row (patched by the compacted pass)
-	__shared__ cb_u32 Clist[4][CS_COLS];        // frame columns of the outputs that need the general loop
-	if (A.overflow && *A.overflow) return;
-	const int lane = threadIdx.x & 63;
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	float *__restrict__ V = Vring[wv];
-	cb_u32 *__restrict__ M = Mring[wv];
-	float *__restrict__ R = Rrow[wv];
-	cb_u32 *__restrict__ CL = Clist[wv];
-	const int H = A.H, W = A.W, direction = A.direction;
-	const int HWi = H * W;
-	// wave -> (region, d): as cbca_strip_kernel (four consecutive planes per block, the blocks of an XCD walk all plane
-	// groups of a region before the next region)
-	const int dgroups = (A.nd + 3) >> 2;
-	const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
-	const int region = (kb / dgroups) * 8 + xcd;
-	const int d = A.d0 + (kb % dgroups) * 4 + wv;
-	if (region >= A.gx * A.gy || d >= A.d0 + A.nd) return;
-	const int cx = region % A.gx, cy = region / A.gx;
-	const int sh = d * direction;
-	const int xs = cx * C2_STEP - C2_HALO + 4 * lane;   // image column of this lane's first column
-	const int y0 = cy * A.rb, y1 = min(H, y0 + A.rb);
-	const int ra = y0 - CS_UP;
-	const int plane_bytes = HWi * 4;
-	const cb_u32 OOB = 0x80000000u;
-	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
-	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
-	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
-	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
-	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
-	const bool full_in = xs >= 0 && xs + 3 < W;
-	const bool has_out = lane >= 1 && lane <= 62;
-	const bool full_out = has_out && xs + 3 < W;
-	const bool any_out = has_out && xs < W;
-	// per output: the column exists / its shifted partner is inside the image (adcensus.cu:353-354) -- lane masks
-	bool valid[4], inr[4];
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const int x = xs + j;
-		valid[j] = has_out && x < W;
-		inr[j] = x + sh >= 0 && x + sh < W;
-	}
-
-	struct Stage { cb_u4 v, a, b; };
-	auto fetch = [&](Stage &st, int r) {  // row r of the plane -> registers (rows outside the image: zeros)
-		const bool rok = r >= 0 && r < H;
-		const int base = r * W + xs;
-		if (full_in) {
-			st.v = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)base * 4u : OOB, 0, VOL_AUX);
-		} else {  // image edges: per column
-			cb_u32 t[4];
-#pragma unroll
-			for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_raw_buffer_load_b32(rv, (rok && xs + k >= 0 && xs + k < W) ? (cb_u32)(base + k) * 4u : OOB, 0, 0);
-			st.v = cb_u4{t[0], t[1], t[2], t[3]};
-		}
-		st.a = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
-		st.b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
-	};
-
-	// the reference's loop for the output in frame column c of row yo (any support)
-	auto general = [&](int yo, int c, int u, int dn, int lo_row, int hi_row) -> float {
-		const int x = cx * C2_STEP - C2_HALO + c;
-		float sum = 0;
-		int cnt = 0;
-		for (int q = yo - u; q <= yo + dn; ++q) {
-			const bool row_in = q >= lo_row && q <= hi_row;
-			const int rowo = slot(q) * CS_COLS;
-			cb_u32 mm;
-			if (row_in) mm = M[rowo + c];
-			else {
-				const int g = q * W + x;
-				mm = bytemin4(A.p0[g], A.p1[g + sh]);
-			}
-			const int l = (int)(mm & 0xff), rg = (int)((mm >> 8) & 0xff);
-			const int n = l + rg + 1;
-			if (row_in && c - l >= 0 && c + rg < CS_COLS) {
-				const float *row = V + rowo + c - l;
-				int k = 0;
-				for (; k + 4 <= n; k += 4) {
-					const float v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3];
-					sum += v0; sum += v1; sum += v2; sum += v3;
-				}
-				if (k < n) {
-					const float v0 = row[k];
-					const float v1 = row[min(k + 1, n - 1)], v2 = row[min(k + 2, n - 1)];
-					sum += v0;
-					if (k + 1 < n) sum += v1;
-					if (k + 2 < n) sum += v2;
-				}
-			} else {  // run leaves the staged frame: from global memory, same order
-				const float *row = A.vin + (size_t)d * HWi + q * W + x - l;
-				for (int k = 0; k < n; ++k) sum += row[k];
-			}
-			cnt += n;
-		}
-		return sum / (float)cnt;
-	};
-
-	// need-the-general-loop accumulators, one lane mask per output column: accA = row (newest - 1) so far, accB = newest
-	bool accA[4] = {true, true, true, true}, accB[4] = {true, true, true, true};
-
-	auto commit = [&](const Stage &st, int r, C2Row &w, bool (&need)[4]) {
-		const int o = slot(r) * CS_COLS + 4 * lane;
-		*(cb_u4 *)(V + o) = st.v;
-		const cb_u4 m = bytemin4x4_sdwa(st.a, st.b);
-		*(cb_u4 *)(M + o) = m;
-		const float v0 = __uint_as_float(st.v.x), v1 = __uint_as_float(st.v.y), v2 = __uint_as_float(st.v.z), v3 = __uint_as_float(st.v.w);
-		const float l3 = lane_from_below(v3, 0.0f), r0 = lane_from_above(v0, 0.0f);
-		w.A = cb_f2{l3, v0}; w.B = cb_f2{v0, v1}; w.C = cb_f2{v1, v2}; w.D = cb_f2{v2, v3}; w.E = cb_f2{v3, r0};
-		// minimal support of output (y, x) <=> own arms all 1 and the rows above / below have left = right = 1 in column x
-		const cb_u32 mj[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const bool all_ne = mj[j] != 0x01010101u;
-			const bool lr_ne = (mj[j] & 0xffffu) != 0x0101u;
-			need[j] = accA[j] || lr_ne;      // row r-1 is complete: lr(r-2) | all(r-1) | lr(r)
-			accA[j] = accB[j] || all_ne;     // row r so far: lr(r-1) | all(r)
-			accB[j] = lr_ne;                 // row r+1 so far: lr(r)
-		}
-	};
-
-	auto output = [&](int yo, const C2Row &up, const C2Row &own, const C2Row &dn_, const bool (&need)[4]) {
-		// minimal 3x3 sums of the four outputs, two packed chains in the reference's order
-		cb_f2 s01 = cb_f2{0.0f, 0.0f}, s23 = cb_f2{0.0f, 0.0f};
-		s01 += up.A; s01 += up.B; s01 += up.C;
-		s23 += up.C; s23 += up.D; s23 += up.E;
-		s01 += own.A; s01 += own.B; s01 += own.C;
-		s23 += own.C; s23 += own.D; s23 += own.E;
-		s01 += dn_.A; s01 += dn_.B; s01 += dn_.C;
-		s23 += dn_.C; s23 += dn_.D; s23 += dn_.E;
-		const cb_f2 q01 = div9_pk(s01), q23 = div9_pk(s23);
-		float res[4] = {q01.x, q01.y, q23.x, q23.y};
-		const float sums[4] = {s01.x, s01.y, s23.x, s23.y};
-		const float ownv[4] = {own.B.x, own.B.y, own.D.x, own.D.y};
-		bool nj[4], odd = false;
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			nj[j] = need[j] && inr[j] && valid[j];
-			const bool used = !need[j] && inr[j] && valid[j];
-			odd = odd || (used && !div9_in_range(sums[j]));
-		}
-		if (__any(odd)) {  // a sum outside the range the packed form is proven for (zero, tiny, huge, inf, nan): IEEE divide
-#pragma unroll
-			for (int j = 0; j < 4; ++j) res[j] = sums[j] / 9.0f;
-		}
-#pragma unroll
-		for (int j = 0; j < 4; ++j) res[j] = inr[j] ? res[j] : ownv[j];   // adcensus.cu:353-354: copied through
-		if (__any(nj[0] || nj[1] || nj[2] || nj[3])) {
-			// compact the (lane, j) pairs that need the general loop into CL[0..n)
-			int n = 0;
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const uint64_t bal = __ballot(nj[j]);
-				const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((cb_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)bal, 0));
-				if (nj[j]) CL[pos] = (cb_u32)(4 * lane + j);
-				n += __builtin_popcountll(bal);
-			}
-			*(cb_f4 *)(R + 4 * lane) = cb_f4{res[0], res[1], res[2], res[3]};
-			const int lo_row = max(max(ra, 0), yo + CS_LA - (CS_RING - 1)), hi_row = min(H - 1, yo + CS_LA);
-			for (int e0 = 0; e0 < n; e0 += 64) {
-				const int e = e0 + lane;
-				if (e < n) {
-					const int c = (int)CL[e];
-					// Window form: supports inside rows y-2 .. y+LA of the ring and columns x-WR .. x+WR are summed from ONE batch
-					// of LDS reads: every tap of the window is read, the taps outside the support add -0.0f (x + -0.0f == x
-					// exactly, so the chain of additions is the reference's), rows ascending and x ascending.
-					constexpr int NWR = 3 + CS_LA;
-					cb_u32 mm[NWR];
-					float tv[NWR][2 * CS_WR + 1];
-#pragma unroll
-					for (int k = 0; k < NWR; ++k) {
-						const int ro_ = slot(yo + k - 2) * CS_COLS + c;
-						mm[k] = M[ro_];
-#pragma unroll
-						for (int t = 0; t < 2 * CS_WR + 1; ++t) tv[k][t] = V[ro_ + t - CS_WR];
-					}
-					const int u = (int)((mm[2] >> 16) & 0xff), dn = (int)(mm[2] >> 24);   // own row: k = 2
-					bool ok = u <= 2 && dn <= CS_LA && yo - u >= lo_row && yo + dn <= hi_row;
-					float sum = 0;
-					int cnt = 0;
-#pragma unroll
-					for (int k = 0; k < NWR; ++k) {
-						const int rel = k - 2;
-						const bool act = rel >= -u && rel <= dn;
-						const int l = (int)(mm[k] & 0xff), rg = (int)((mm[k] >> 8) & 0xff);
-						ok = ok && (!act || (l <= CS_WR && rg <= CS_WR && c - l >= 0 && c + rg < CS_COLS));
-						const int la = act ? l : -1, rga = act ? rg : -1;
-#pragma unroll
-						for (int t = 0; t < 2 * CS_WR + 1; ++t) {
-							const int dx = t - CS_WR;
-							const bool in = dx < 0 ? la >= -dx : (dx == 0 ? act : rga >= dx);
-							sum += in ? tv[k][t] : -0.0f;
-						}
-						cnt += act ? l + rg + 1 : 0;
-					}
-					R[c] = ok ? sum / (float)cnt : general(yo, c, u, dn, lo_row, hi_row);
-				}
-			}
-			const cb_f4 rr = *(const cb_f4 *)(R + 4 * lane);
-			res[0] = rr.x; res[1] = rr.y; res[2] = rr.z; res[3] = rr.w;
-		}
-		const int ob = yo * W + xs;
-		if (full_out) {
-			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
-			                                       ro, (cb_u32)ob * 4u, 0, VOL_AUX);
-		} else if (any_out) {
-#pragma unroll
-			for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[j]), ro, xs + j < W ? (cb_u32)(ob + j) * 4u : OOB, 0, 0);
-		}
-	};
-
-	Stage st[PF];
-	C2Row w[PF];
-#pragma unroll
-	for (int u = 0; u < PF; ++u) {
-		fetch(st[u], ra + u);
-		w[u].A = w[u].B = w[u].C = w[u].D = w[u].E = cb_f2{0.0f, 0.0f};
-	}
-	const int last = y1 - 1 + CS_LA;   // newest row that has to be committed for the last output row
-	for (int g = ra; g <= last; g += PF) {
-#pragma unroll
-		for (int u = 0; u < PF; ++u) {
-			const int r = g + u;
-			bool need[4];
-			commit(st[u], r, w[u], need);
-			fetch(st[u], r + PF);
-			const int yo = r - CS_LA;
-			if (yo >= y0 && yo < y1) output(yo, w[(u + 1) % PF], w[(u + 2) % PF], w[u], need);
-		}
-	}
-}
-
 size_t cbca_scratch_bytes(int H, int W) { return (((size_t)2 * H * W + 3 * CS_PAD + 1) * sizeof(uint32_t) + 255) & ~(size_t)255; }
 
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st)

@@ -30,7 +30,6 @@ struct CbcaCfg {
 	int rb = 0;        // output rows per strip (0 = auto)
 	int nt = -1;       // volume cache policy: -1 auto, 0 default, 1 non-temporal
 	int d0 = 0, nd = 0;// planes [d0, d0 + nd) only (nd = 0: all)
-	int fused = 0;     // 1: two iterations per launch (cbca_fused2), vout = cbca(cbca(vin))
 };
 
 // ---- wave64 cross-lane primitives (DPP, no LDS round trip) -------------------

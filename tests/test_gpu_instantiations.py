@@ -3,8 +3,7 @@ test hooks of the C ABI (mc_cbca_ws_cfg, mc_transpose_cfg) and compared with the
 
   * rows per CBCA strip rb in {16, 25, 40} (KITTI size runs 25, 1000x1500 runs 40; small shapes pick 16),
   * the non-temporal instantiations of the CBCA strip kernel and of the layout transposes (selected above 768 MB),
-  * plane sub-ranges of a volume,
-  * the three-operation division by 9 of the register-window kernels against the IEEE quotient, exhaustively.
+  * plane sub-ranges of a volume.
 (tests/test_gpu_fullsize.py checks the same code at the real sizes against the reference's kernels.)"""
 import numpy as np
 import pytest
@@ -60,19 +59,6 @@ def test_transposes_forced_cache_policy(mc, R, Cn, nt):
     assert same_bits(out.cpu().numpy(), (a * np.float32(0.25)).T)
 
 
-def test_division_by_nine_is_the_ieee_quotient_for_every_float(mc):
-    """all 2^32 bit patterns: inside the guarded range the packed q = s*r, e = fma(-9,q,s), q' = fma(e,r,q) form must
-    equal s / 9.0f; outside it the kernels take the IEEE divide (and the count there shows the guard is needed)."""
-    bad_in = bad_out = 0
-    for first in range(0, 1 << 32, 1 << 30):
-        i, o, ex = mc.adcensus.selftest_div9(first, 1 << 30)
-        assert i == 0, "mismatch inside the guarded range, e.g. bits 0x%08x" % ex
-        bad_in += i
-        bad_out += o
-    assert bad_in == 0
-    assert bad_out > 0   # inf / huge / tiny inputs do differ: the guard is not decorative
-
-
 def test_left_only_skips_the_right_volume_without_changing_the_left(mc):
     """mc_params.left_only: dataset mb outside `-a predict` runs direction -1 only (main.lua:953-955); disp is the same"""
     H, W, D = 40, 120, 24
@@ -93,36 +79,3 @@ def test_left_only_skips_the_right_volume_without_changing_the_left(mc):
     a = mc.stereo_predict_fused(xb, prk, D, raw=raw)["disp"].cpu().numpy()
     b = mc.stereo_predict_fused(xb, dict(prk, left_only=1), D, raw=raw)["disp"].cpu().numpy()
     assert same_bits(a, b)
-
-
-def _images(mk, H, W, D):
-    if mk == "smooth":
-        return smooth_pair(H, W, min(D, 8), seed=H)
-    if mk == "blocky":
-        return blocky_pair(H, W, seed=W)
-    if mk == "random":
-        return random_pair(H, W, seed=3)
-    x0 = np.zeros((H, W), np.float32)
-    x1 = np.zeros((H, W), np.float32)
-    x1[H // 2:, W // 3:] = 2.0  # one edge so that left and right arms differ
-    return x0, x1
-
-
-@pytest.mark.parametrize("H,W,D", [(50, 200, 12), (33, 131, 7), (16, 64, 8), (70, 90, 20), (20, 241, 6), (45, 485, 5),
-                                   (9, 1010, 3), (83, 240, 3), (3, 5, 2), (130, 250, 4)])
-@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.02), ("smooth", 14, 0.3), ("blocky", 14, 0.2), ("flat", 13, 1.0),
-                                        ("random", 5, 0.13), ("blocky", 40, 0.3)])
-@pytest.mark.parametrize("rb,nt", [(0, -1), (24, 1), (64, 0)])
-def test_cbca_two_iterations_fused(mc, oracle, H, W, D, mk, L1, tau1, rb, nt):
-    """cbca_fused2_kernel: vol_out = cbca(cbca(vol_in)) in ONE launch, against the oracle applied twice.  Strip edges
-    (W around multiples of 240, W % 4 != 0), row chunks, D odd, supports from the minimal 3x3 (registers) through the
-    window form (LDS rings) to arms far beyond the rings (stage 1: global fallback; stage 2: nested rebuild from V_k)."""
-    x0, x1 = _images(mk, H, W, D)
-    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
-    vl, vr = raw_volumes(D, H, W, seed=13)
-    for direction, vol in ((-1, vl), (1, vr)):
-        want = oracle.cbca(x0c, x1c, oracle.cbca(x0c, x1c, vol, direction), direction)
-        out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=nt, fused=1)
-        got = out.cpu().numpy()
-        assert same_bits(got, want), diff_report(got, want, "fused cbca x2 dir=%d" % direction)
