@@ -177,6 +177,50 @@ __global__ void __launch_bounds__(256) stripcopy(const float *vin, const uint32_
 	if (chk && acc == 0x12345u) chk[0] = acc;
 }
 
+// tiled variant: the same strip walk, but the volume is stored strip-major -- [d][strip][row][256 staged columns] --
+// so that a wave streams ONE contiguous region (what a tiled internal layout between cbca iterations would give)
+template <bool PL>
+__global__ void __launch_bounds__(256) tiledcopy(const float *vin, const uint32_t *p0, const uint32_t *p1, float *vout, int D, int H,
+                                                 int W, int RB, int gxs, int gyc, unsigned *chk)
+{
+	typedef unsigned u4 __attribute__((ext_vector_type(4)));
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int xcd = blockIdx.x & 7; int w = (blockIdx.x >> 3) * 4 + wv; const int D8 = D / 8;
+	const int cx = w % gxs; w /= gxs; const int cy = w % gyc; const int d = (w / gyc) * 8 + xcd;
+	if (d >= D || cy >= gyc) return;
+	const int xs = cx * 248 - 4 + lane * 4;
+	const int HWi = H * W;
+	const size_t tile = (size_t)H * 256;   // floats per (d, strip)
+	const float *tin = vin + ((size_t)d * gxs + cx) * tile;
+	float *tout = vout + ((size_t)d * gxs + cx) * tile;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)tin, 0, (int)(tile * 4), 0x00020000);
+	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)tout, 0, (int)(tile * 4), 0x00020000);
+	const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void *)p0, 0, HWi * 4, 0x00020000);
+	const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void *)p1, 0, HWi * 4, 0x00020000);
+	const int y0 = cy * RB, y1 = min(H, y0 + RB);
+	const bool in = xs >= 0 && xs + 3 < W;
+	unsigned acc = 0;
+	for (int y = y0; y < y1; y += 4) {
+		u4 v[4], a[4], b[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const unsigned toff = (y + k < y1) ? (unsigned)((y + k) * 256 + lane * 4) * 4u : 0x80000000u;
+			const unsigned off = (y + k < y1 && in) ? (unsigned)((y + k) * W + xs) * 4u : 0x80000000u;
+			v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, toff, 0, 0);
+			if (PL) {
+				a[k] = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, 0);
+				b[k] = __builtin_amdgcn_raw_buffer_load_b128(r1, (y + k < y1 && in && xs - d >= 0) ? off - (unsigned)d * 4u : 0x80000000u, 0, 0);
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			if (PL) { acc += a[k].x ^ b[k].y; if ((a[k].z & b[k].w) == 0xdeadbeefu) v[k].x = 0; }
+			__builtin_amdgcn_raw_buffer_store_b128(v[k], ro, (y + k < y1) ? (unsigned)((y + k) * 256 + lane * 4) * 4u : 0x80000000u, 0, 0);
+		}
+	}
+	if (chk && acc == 0x12345u) chk[0] = acc;
+}
+
 template <typename F> float timeit(F f, int reps)
 {
 	hipEvent_t e0, e1;
@@ -228,6 +272,18 @@ int main()
 	printf("stripcopy order=%d p-loads=%d RB=%d: %.3f ms  %.0f GB/s (2V)\n", ORDER, PL, RB, ms, GB / ms * 1e3); } while (0)
 	RUNS(0, false, 40); RUNS(0, true, 40); RUNS(1, true, 40); RUNS(2, true, 40); RUNS(3, true, 40);
 	RUNS(0, true, 100); RUNS(2, true, 100); RUNS(3, true, 100); RUNS(3, true, 200);
+	{
+		// tiled layout: 7 strips of 256 stored columns per row instead of 1500 (needs 1.2x the bytes: reuse the buffers for D*0.8 planes)
+		const int Dt = 200, gxs = (W + 247) / 248;
+		for (int RB : {40, 100}) {
+			const int gyc = (H + RB - 1) / RB; const int nw = gxs * gyc * Dt;
+			const double GBt = 2.0 * Dt * gxs * H * 256 * 4 / 1e9;
+			float ms = timeit([&] { hipLaunchKernelGGL((tiledcopy<true>), dim3((nw + 3) / 4 + 8), dim3(256), 0, 0, a, p1, p1, o, Dt, H, W, RB, gxs, gyc, (unsigned *)nullptr); }, 5);
+			printf("tiledcopy p-loads=1 RB=%d (D=%d): %.3f ms  %.0f GB/s of tile bytes, %.0f GB/s of useful (248/256) bytes\n", RB, Dt, ms, GBt / ms * 1e3, GBt / ms * 1e3 * 248 / 256);
+			ms = timeit([&] { hipLaunchKernelGGL((tiledcopy<false>), dim3((nw + 3) / 4 + 8), dim3(256), 0, 0, a, p1, p1, o, Dt, H, W, RB, gxs, gyc, (unsigned *)nullptr); }, 5);
+			printf("tiledcopy p-loads=0 RB=%d (D=%d): %.3f ms  %.0f GB/s of tile bytes\n", RB, Dt, ms, GBt / ms * 1e3);
+		}
+	}
 	{ float ms = timeit([&] { CK(hipMemcpyAsync(o, a, n * 4, hipMemcpyDeviceToDevice, 0)); }, 5); printf("memcpy D2D: %.3f ms %.0f GB/s\n", ms, GB / ms * 1e3); }
 	return 0;
 }

@@ -79,3 +79,29 @@ def test_left_only_skips_the_right_volume_without_changing_the_left(mc):
     a = mc.stereo_predict_fused(xb, prk, D, raw=raw)["disp"].cpu().numpy()
     b = mc.stereo_predict_fused(xb, dict(prk, left_only=1), D, raw=raw)["disp"].cpu().numpy()
     assert same_bits(a, b)
+
+
+def test_cbca_special_values(mc, oracle):
+    """zeros, negative zeros, denormals, huge values, infinities and NaNs INSIDE the valid region, on a mix of minimal,
+    window-form and larger supports: NaN / inf propagate as in the reference, and a support of nothing but -0.0 sums to
+    +0.0 (the reference's accumulator starts at +0.0, adcensus.cu:356)."""
+    H, W, D = 40, 260, 6
+    x0, x1 = random_pair(H, W, seed=8)
+    x0c, x1c = oracle.cross(x0, 14, 0.35), oracle.cross(x1, 14, 0.35)
+    vl, _ = raw_volumes(D, H, W, seed=3)
+    rng = np.random.default_rng(1)
+    vl[0, :, 20:] = 0.0
+    vl[1, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-42)      # denormals
+    vl[2, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-30)      # tiny normals
+    vl[3, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(3e38)       # sums overflow
+    vl[4, 10, 100] = np.inf
+    vl[4, 20, 150] = np.nan
+    vl[5, :, 20:] = -rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-38)
+    vl[5, 25:, 20:] = -0.0
+    with np.errstate(all="ignore"):
+        want = oracle.cbca(x0c, x1c, vl, -1)
+    for rb, nt in ((0, -1), (25, 1)):
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=rb, nt=nt)
+        got = out.cpu().numpy()
+        assert same_bits(got, want), diff_report(got, want, "special values rb=%d nt=%d" % (rb, nt))
