@@ -259,66 +259,54 @@ template <int K> __device__ __forceinline__ void ray_rank_step(float v, int inb,
 	eq += (oin && ov == v) ? 1 : 0;
 }
 
-// A block first looks at its 256 pixels with one thread each: pixels that are not mismatches are copied through, the
-// (few) mismatch pixels are collected in LDS and only those get the 16 ray lanes, 16 pixels per pass.
 __global__ void __launch_bounds__(256) interp_mis_rays_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
                                                               float *__restrict__ out, int64_t size, int H, int W)
 {
 	// direction (dx, dy) of ray k, adcensus.cu:1013-1030
 	const float dirx[16] = {0, -0.5f, -1, -1, -1, -1, -1, -0.5f, 0, 0.5f, 1, 1, 1, 1, 1, 0.5f};
 	const float diry[16] = {1, 1, 1, 0.5f, 0, -0.5f, -1, -1, -1, -1, -1, -0.5f, 0, 0.5f, 1, 1};
-	__shared__ int list[256];
-	__shared__ int count;
-	if (threadIdx.x == 0) count = 0;
-	__syncthreads();
-	const int64_t base = (int64_t)blockIdx.x * 256;
-	{
-		const int64_t id = base + threadIdx.x;
-		if (id < size) {
-			if (outlier[id] == 2) list[atomicAdd(&count, 1)] = (int)threadIdx.x;   // order is irrelevant: pixels are independent
-			else out[id] = d0[id];
-		}
-	}
-	__syncthreads();
-	const int n_mis = count;
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t id = t >> 4;
 	const int ray = (int)(threadIdx.x & 15);
-	const float dx = dirx[ray], dy = diry[ray];
-	for (int e0 = 0; e0 < n_mis; e0 += 16) {
-		const int e = e0 + (int)(threadIdx.x >> 4);
-		if (e >= n_mis) continue;   // uniform over the 16 lanes of a DPP row
-		const int64_t id = base + list[e];
-		const int x = (int)(id % W), y = (int)(id / W);
-		float xx = (float)x, yy = (float)y;
-		int xi = x, yi = y;
-		while (0 <= yi && yi < H && 0 <= xi && xi < W && outlier[yi * W + xi] == 2) {
-			xx += dx;
-			yy += dy;
-			xi = (int)roundf(xx);
-			yi = (int)roundf(yy);
-		}
-		const int inb = (0 <= yi && yi < H && 0 <= xi && xi < W) ? 1 : 0;
-		const float v = inb ? d0[yi * W + xi] : 0.0f;
-		int less = 0, eq = inb;
-		ray_rank_step<1>(v, inb, less, eq); ray_rank_step<2>(v, inb, less, eq); ray_rank_step<3>(v, inb, less, eq);
-		ray_rank_step<4>(v, inb, less, eq); ray_rank_step<5>(v, inb, less, eq); ray_rank_step<6>(v, inb, less, eq);
-		ray_rank_step<7>(v, inb, less, eq); ray_rank_step<8>(v, inb, less, eq); ray_rank_step<9>(v, inb, less, eq);
-		ray_rank_step<10>(v, inb, less, eq); ray_rank_step<11>(v, inb, less, eq); ray_rank_step<12>(v, inb, less, eq);
-		ray_rank_step<13>(v, inb, less, eq); ray_rank_step<14>(v, inb, less, eq); ray_rank_step<15>(v, inb, less, eq);
-		const uint64_t bal = __ballot(inb != 0);
-		const int n = __builtin_popcount((unsigned)((bal >> ((threadIdx.x & 48))) & 0xffffu));
-		if (n == 0) {
-			if (ray == 0) out[id] = d0[id];
-			continue;
-		}
-		const int want = n / 2;
-		if (inb && less <= want && want < less + eq) out[id] = v;   // lanes that qualify hold the same value
+	if (id >= size) return;
+	const bool mis = outlier[id] == 2;
+	if (!mis) {
+		if (ray == 0) out[id] = d0[id];
+		return;
 	}
+	const int x = (int)(id % W), y = (int)(id / W);
+	const float dx = dirx[ray], dy = diry[ray];
+	float xx = (float)x, yy = (float)y;
+	int xi = x, yi = y;
+	while (0 <= yi && yi < H && 0 <= xi && xi < W && outlier[yi * W + xi] == 2) {
+		xx += dx;
+		yy += dy;
+		xi = (int)roundf(xx);
+		yi = (int)roundf(yy);
+	}
+	const int inb = (0 <= yi && yi < H && 0 <= xi && xi < W) ? 1 : 0;
+	const float v = inb ? d0[yi * W + xi] : 0.0f;
+	// all 16 lanes of this pixel are here (mis is uniform over the row of 16)
+	int less = 0, eq = inb;
+	ray_rank_step<1>(v, inb, less, eq); ray_rank_step<2>(v, inb, less, eq); ray_rank_step<3>(v, inb, less, eq);
+	ray_rank_step<4>(v, inb, less, eq); ray_rank_step<5>(v, inb, less, eq); ray_rank_step<6>(v, inb, less, eq);
+	ray_rank_step<7>(v, inb, less, eq); ray_rank_step<8>(v, inb, less, eq); ray_rank_step<9>(v, inb, less, eq);
+	ray_rank_step<10>(v, inb, less, eq); ray_rank_step<11>(v, inb, less, eq); ray_rank_step<12>(v, inb, less, eq);
+	ray_rank_step<13>(v, inb, less, eq); ray_rank_step<14>(v, inb, less, eq); ray_rank_step<15>(v, inb, less, eq);
+	const uint64_t bal = __ballot(inb != 0);
+	const int n = __builtin_popcount((unsigned)((bal >> ((threadIdx.x & 48))) & 0xffffu));
+	if (n == 0) {
+		if (ray == 0) out[id] = d0[id];
+		return;
+	}
+	const int want = n / 2;
+	if (inb && less <= want && want < less + eq) out[id] = v;   // lanes that qualify hold the same value
 }
 
 int interpolate_mismatch(const float *d0, const float *outlier, float *out, int H, int W, hipStream_t st)
 {
 	const int64_t size = (int64_t)H * W;
-	hipLaunchKernelGGL(interp_mis_rays_kernel, dim3(cdiv(size, 256)), dim3(256), 0, st, d0, outlier, out, size, H, W);
+	hipLaunchKernelGGL(interp_mis_rays_kernel, dim3(cdiv(size * 16, 256)), dim3(256), 0, st, d0, outlier, out, size, H, W);
 	return check_launch("interpolate_mismatch");
 }
 
