@@ -256,24 +256,6 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
                    int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
                    int rb, int nt, int d0, int nd, void *stream);
 
-/* TWO cbca iterations in one pass, vol_out = cbca(cbca(vol_in)): the kernel mc_predict uses for pairs of iterations on
- * images whose supports are mostly the minimal 3x3.  Every output is classified once per pair and direction (lane masks +
- * one 32-bit support descriptor per flagged output + counters, held in `cls`, mc_cbca_class_bytes); the intermediate
- * volume never reaches memory.  This entry point runs arm packing + classification + ONE fused launch (arms must not
- * exceed 254 pixels); force = 1 ignores the density gate (otherwise the launch does nothing, and says so by leaving
- * vol_out untouched, when more than 5 % of the outputs are flagged or 0.02 % do not fit the 5 x 5 window).
- * Bit-identical to two calls of mc_cbca. */
-size_t mc_cbca_class_bytes(int D, int H, int W);
-int mc_cbca_fused2_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
-                       int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
-                       void *cls, size_t cls_bytes, int rb, int nt, int force, void *stream);
-
-/* Walks `count` consecutive float bit patterns from `first` on the device and compares the three-operation division
- * by 9 used by the fused cbca kernel with the IEEE quotient.  counters (DEVICE, 3 x uint64, zeroed by the caller):
- * [0] mismatches inside the guarded magnitude range (must stay 0), [1] mismatches outside it (the kernel takes the IEEE
- * divide there), [2] one offending bit pattern. */
-int mc_selftest_div9(uint32_t first, uint64_t count, unsigned long long *counters, void *stream);
-
 /* (H,W,D)<->(D,H,W) transpose with the cache policy forced (nt as above); scale multiplies every element. */
 int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, int64_t ldin, int64_t ldout,
                      float scale, int nt, void *stream);

@@ -96,28 +96,6 @@ def cbca_cfg(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, d0=0, nd=0):
                              int(rb), int(nt), int(d0), int(nd), _stream()), "cbca_cfg")
 
 
-def cbca_fused2(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, force=1):
-    """Test / bench hook (mc_cbca_fused2_cfg): vol_out = cbca(cbca(vol_in)) in one launch -- arm packing, the once-per-pair
-    classification of every output (lane masks + support descriptors) and the fused two-iteration kernel."""
-    _chk(x0c, x1c, vol_in, vol_out)
-    D, H, W = vol_out.shape[-3:]
-    need_s = lib.mc_cbca_scratch_bytes(H, W)
-    need_c = lib.mc_cbca_class_bytes(D, H, W)
-    scratch = _scratch_for(vol_out.device, need_s + need_c + 256)
-    p = scratch.data_ptr()
-    pc = (p + need_s + 255) // 256 * 256
-    check(lib.mc_cbca_fused2_cfg(_p(x0c), _p(x1c), _p(vol_in), _p(vol_out), D, H, W, int(direction), p, need_s, pc, need_c,
-                                 int(rb), int(nt), int(force), _stream()), "cbca_fused2")
-
-
-def selftest_div9(first, count):
-    """Test hook (mc_selftest_div9): (mismatches inside the guarded range, outside it, one offending bit pattern)."""
-    c = torch.zeros(3, dtype=torch.int64, device="cuda")
-    check(lib.mc_selftest_div9(int(first), int(count), c.data_ptr(), _stream()), "selftest_div9")
-    v = c.cpu().tolist()
-    return v[0], v[1], v[2] & 0xFFFFFFFF
-
-
 def transpose_cfg(inp, out, rows, cols, ldin, ldout, scale=1.0, nt=-1):
     """Test hook (mc_transpose_cfg): the layout kernel with its cache policy forced."""
     _chk(inp, out)

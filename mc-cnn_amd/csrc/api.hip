@@ -39,11 +39,6 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
                      int direction, hipStream_t st);
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
-size_t cbca_class_bytes(int D, int H, int W);
-int cbca_classify(const void *packed, void *cls, int D, int H, int W, int direction, hipStream_t st);
-int cbca_fused2(const void *packed, const void *cls, const float *vin, float *vout, int D, int H, int W, int direction,
-                hipStream_t st, const CbcaCfg &cfg, bool force);
-int div9_selftest(uint32_t first, uint64_t count, unsigned long long *counters, hipStream_t st);
 size_t fc_workspace_bytes(int C, int n_hidden, int H, int W);
 int fc_stack(const float *featL, const float *featR, int C, int H, int W, int D, const float *const *weights,
              const float *const *biases, int n_layers, float *volL, float *volR, void *workspace, hipStream_t st);
@@ -548,39 +543,6 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg);
 	if (rc) return rc;
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
-}
-
-size_t mc_cbca_class_bytes(int D, int H, int W)
-{
-	if (!dims_ok(D, H, W)) return 0;
-	return cbca_class_bytes(D, H, W);
-}
-
-int mc_cbca_fused2_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
-                       void *scratch, size_t scratch_bytes, void *cls, size_t cls_bytes, int rb, int nt, int force, void *stream)
-{
-	MC_REQUIRE(x0c && x1c && vol_in && vol_out && scratch && cls, "mc_cbca_fused2_cfg: null pointer");
-	MC_REQUIRE(vol_in != vol_out, "mc_cbca_fused2_cfg: in-place aggregation is not supported");
-	MC_REQUIRE(dims_ok(D, H, W) && D <= 65535 * 8, "mc_cbca_fused2_cfg: bad dims");
-	MC_REQUIRE(direction == -1 || direction == 1, "mc_cbca_fused2_cfg: direction must be -1 or 1");
-	MC_REQUIRE(scratch_bytes >= cbca_scratch_bytes(H, W) && cls_bytes >= cbca_class_bytes(D, H, W), "mc_cbca_fused2_cfg: scratch too small");
-	MC_REQUIRE((uintptr_t)scratch % 4 == 0 && (uintptr_t)cls % 8 == 0, "mc_cbca_fused2_cfg: misaligned scratch");
-	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_fused2_cfg: image too large for 32-bit plane offsets");
-	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1, "mc_cbca_fused2_cfg: bad rb / nt");
-	hipStream_t st = as_stream(stream);
-	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
-	if (rc) return rc;
-	rc = cbca_classify(scratch, cls, D, H, W, direction, st);
-	if (rc) return rc;
-	CbcaCfg cfg;
-	cfg.rb = rb; cfg.nt = nt;
-	return cbca_fused2(scratch, cls, vol_in, vol_out, D, H, W, direction, st, cfg, force != 0);
-}
-
-int mc_selftest_div9(uint32_t first, uint64_t count, unsigned long long *counters, void *stream)
-{
-	MC_REQUIRE(counters && count >= 1 && count <= ((uint64_t)1 << 32), "mc_selftest_div9: bad arguments");
-	return div9_selftest(first, count, counters, as_stream(stream));
 }
 
 int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, int64_t ldin, int64_t ldout, float scale_, int nt,

@@ -105,91 +105,3 @@ def test_cbca_special_values(mc, oracle):
         mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=rb, nt=nt)
         got = out.cpu().numpy()
         assert same_bits(got, want), diff_report(got, want, "special values rb=%d nt=%d" % (rb, nt))
-
-
-def _images(mk, H, W, D):
-    if mk == "smooth":
-        return smooth_pair(H, W, min(D, 8), seed=H)
-    if mk == "blocky":
-        return blocky_pair(H, W, seed=W)
-    if mk == "random":
-        return random_pair(H, W, seed=3)
-    x0 = np.zeros((H, W), np.float32)
-    x1 = np.zeros((H, W), np.float32)
-    x1[H // 2:, W // 3:] = 2.0  # one edge so that left and right arms differ
-    return x0, x1
-
-
-FUSED_SHAPES = [(50, 200, 12), (33, 131, 7), (16, 64, 8), (70, 90, 20), (20, 241, 6), (45, 485, 5), (9, 1010, 3), (83, 240, 3),
-                (3, 5, 2), (130, 250, 4)]
-
-
-@pytest.mark.parametrize("H,W,D", FUSED_SHAPES)
-@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.02), ("smooth", 14, 0.3), ("random", 5, 0.13), ("random", 14, 0.35)])
-@pytest.mark.parametrize("rb,nt", [(0, -1), (24, 1), (64, 0)])
-def test_cbca_two_iterations_fused(mc, oracle, H, W, D, mk, L1, tau1, rb, nt):
-    """cbca_classify_kernel + cbca_fused2_kernel: vol_out = cbca(cbca(vol_in)) in ONE launch, against the oracle applied twice.
-    Strip edges (W around multiples of 240, W % 4 != 0), row chunks, D % 4 != 0, supports from the minimal 3x3 (registers)
-    through the descriptor-driven window form (LDS rings) to supports beyond it (stage 1: ring / global loop; stage 2:
-    nested rebuild from V_k)."""
-    x0, x1 = _images(mk, H, W, D)
-    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
-    vl, vr = raw_volumes(D, H, W, seed=13)
-    for direction, vol in ((-1, vl), (1, vr)):
-        want = oracle.cbca(x0c, x1c, oracle.cbca(x0c, x1c, vol, direction), direction)
-        out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_fused2(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=nt)
-        got = out.cpu().numpy()
-        assert same_bits(got, want), diff_report(got, want, "fused cbca x2 dir=%d" % direction)
-
-
-@pytest.mark.parametrize("H,W,D", [(33, 131, 3), (50, 250, 2)])
-@pytest.mark.parametrize("mk,L1,tau1", [("blocky", 14, 0.2), ("flat", 13, 1.0), ("blocky", 40, 0.3)])
-def test_cbca_two_iterations_fused_long_arms(mc, oracle, H, W, D, mk, L1, tau1):
-    """images where nearly every support leaves the 5 x 5 window: everything goes through the nested rebuild (slow, exact);
-    and the density gate makes the un-forced launch stand down (vol_out untouched)"""
-    x0, x1 = _images(mk, H, W, D)
-    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
-    vl, _ = raw_volumes(D, H, W, seed=13)
-    want = oracle.cbca(x0c, x1c, oracle.cbca(x0c, x1c, vl, -1), -1)
-    out = torch.full((1, D, H, W), -7.0, device="cuda")
-    mc.adcensus.cbca_fused2(dev(x0c), dev(x1c), dev(vl), out, -1)
-    got = out.cpu().numpy()
-    assert same_bits(got, want), diff_report(got, want, "fused cbca x2, long arms")
-    out.fill_(-7.0)
-    mc.adcensus.cbca_fused2(dev(x0c), dev(x1c), dev(vl), out, -1, force=0)
-    assert bool((out == -7.0).all()), "the gate did not make the fused kernel stand down on a long-armed image"
-
-
-def test_cbca_two_iterations_fused_special_values(mc, oracle):
-    """zeros, negative zeros, denormals, huge values, inf, nan inside the valid region through both fused stages"""
-    H, W, D = 40, 260, 6
-    x0, x1 = random_pair(H, W, seed=8)
-    x0c, x1c = oracle.cross(x0, 14, 0.35), oracle.cross(x1, 14, 0.35)
-    vl, _ = raw_volumes(D, H, W, seed=3)
-    rng = np.random.default_rng(1)
-    vl[0, :, 20:] = 0.0
-    vl[1, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-42)
-    vl[2, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-30)
-    vl[3, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(3e38)
-    vl[4, 10, 100] = np.inf
-    vl[4, 20, 150] = np.nan
-    vl[5, :, 20:] = -rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-38)
-    vl[5, 25:, 20:] = -0.0
-    with np.errstate(all="ignore"):
-        want = oracle.cbca(x0c, x1c, oracle.cbca(x0c, x1c, vl, -1), -1)
-    out = torch.full((1, D, H, W), -7.0, device="cuda")
-    mc.adcensus.cbca_fused2(dev(x0c), dev(x1c), dev(vl), out, -1)
-    got = out.cpu().numpy()
-    assert same_bits(got, want), diff_report(got, want, "fused special values")
-
-
-def test_division_by_nine_is_the_ieee_quotient_for_every_float(mc):
-    """all 2^32 bit patterns: inside the guarded range the packed q = s*r, e = fma(-9,q,s), q' = fma(e,r,q) form must
-    equal s / 9.0f; outside it the kernel takes the IEEE divide (and the count there shows the guard is needed)."""
-    bad_out = 0
-    for first in range(0, 1 << 32, 1 << 30):
-        i, o, ex = mc.adcensus.selftest_div9(first, 1 << 30)
-        assert i == 0, "mismatch inside the guarded range, e.g. bits 0x%08x" % ex
-        bad_out += o
-    assert bad_out > 0   # inf / huge / tiny inputs do differ: the guard is not decorative
