@@ -82,6 +82,15 @@ int mc_fc_stack(const float *featL, const float *featR, int C, int H, int W, int
                 const float *const *weights, const float *const *biases, const int *layer_out, int n_layers,
                 float *volL, float *volR, void *workspace, size_t workspace_bytes, void *stream);
 
+/* One layer of the feature net net_te: cudnn.SpatialConvolution(Cin, Cout, 3, 3, 1, 1, 1, 1) [+ cudnn.ReLU]
+ * (main.lua:681-686 arch slow, 727-746 arch fast with the test-time padding of 1).  in (N,Cin,H,W), weight
+ * (Cout,Cin,3,3), bias (Cout), out (N,Cout,H,W), Cout <= 128; fp32 on the matrix cores (implicit GEMM over the 9 taps).
+ * `workspace` (mc_conv3x3_workspace_bytes) receives the weights re-laid per tap.  The reference's cuDNN picks its
+ * algorithm at run time (cudnn.benchmark, main.lua:330): parity is by tolerance, not bit-exact. */
+size_t mc_conv3x3_workspace_bytes(int Cin, int Cout);
+int mc_conv3x3(const float *in, const float *weight, const float *bias, float *out, int N, int Cin, int Cout, int H, int W,
+               int relu, void *workspace, size_t workspace_bytes, void *stream);
+
 /* fix_border(net, vol, direction), main.lua:922-927: n = (window-1)/2 columns. */
 int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream);
 

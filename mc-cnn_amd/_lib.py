@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libmcadcensus.so")
 
 # every symbol include/mc_adcensus.h declares
 SYMBOLS = [
-    "mc_version", "mc_last_error", "mc_fill_nan", "mc_stereo_join", "mc_ad", "mc_census_scratch_bytes", "mc_census_ws", "mc_fc_stack_workspace_bytes", "mc_fc_stack",
+    "mc_version", "mc_last_error", "mc_fill_nan", "mc_stereo_join", "mc_ad", "mc_census_scratch_bytes", "mc_census_ws", "mc_fc_stack_workspace_bytes", "mc_fc_stack", "mc_conv3x3_workspace_bytes", "mc_conv3x3",
     "mc_fix_border",
     "mc_cross", "mc_cbca", "mc_cbca_scratch_bytes", "mc_cbca_ws", "mc_sgm2_tmp_bytes", "mc_sgm2", "mc_dhw_to_hwd", "mc_hwd_to_dhw", "mc_scale",
     "mc_argmin", "mc_spatial_argmin", "mc_outlier_detection", "mc_interpolate_occlusion",
@@ -34,6 +34,7 @@ def _load():
     lib.mc_census_scratch_bytes.restype = C.c_size_t
     lib.mc_fc_stack_workspace_bytes.restype = C.c_size_t
     lib.mc_predict_workspace_bytes.restype = C.c_size_t
+    lib.mc_conv3x3_workspace_bytes.restype = C.c_size_t
     lib.mc_predict_workspace_bytes.argtypes = [C.POINTER(McParams), C.c_int, C.c_int, C.c_int, C.c_int]
     vp, i, f, i64, sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
     sig = {
@@ -44,6 +45,8 @@ def _load():
         "mc_census_ws": [vp, vp, vp, i, i, i, i, i, vp, sz, vp],
         "mc_fc_stack_workspace_bytes": [i, i, i, i],
         "mc_fc_stack": [vp, vp, i, i, i, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(i), i, vp, vp, vp, sz, vp],
+        "mc_conv3x3_workspace_bytes": [i, i],
+        "mc_conv3x3": [vp, vp, vp, vp, i, i, i, i, i, i, vp, sz, vp],
         "mc_fix_border": [vp, i, i, i, i, i, vp],
         "mc_cross": [vp, vp, i, i, i, f, vp],
         "mc_cbca": [vp, vp, vp, vp, i, i, i, i, vp],
@@ -74,7 +77,7 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         if name not in ("mc_sgm2_tmp_bytes", "mc_cbca_scratch_bytes", "mc_census_scratch_bytes",
-                        "mc_fc_stack_workspace_bytes"):
+                        "mc_fc_stack_workspace_bytes", "mc_conv3x3_workspace_bytes"):
             fn.restype = C.c_int
     if lib.mc_version() != 3:
         raise ImportError("mc-cnn_amd: ABI version mismatch")

@@ -58,6 +58,21 @@ def census(x0, x1, out, direction):
           "census")
 
 
+def conv3x3(x, weight, bias, relu, out=None):
+    """cudnn.SpatialConvolution(Cin, Cout, 3, 3, 1, 1, 1, 1) [+ ReLU] of net_te (main.lua:681-686, 727-746) through
+    mc_conv3x3 (fp32 MFMA implicit GEMM).  x (N,Cin,H,W), weight (Cout,Cin,3,3), bias (Cout)."""
+    _chk(x, weight, bias)
+    N, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    if out is None:
+        out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
+    need = lib.mc_conv3x3_workspace_bytes(Cin, Cout)
+    ws = _scratch_for(x.device, need)
+    check(lib.mc_conv3x3(_p(x), _p(weight), _p(bias), _p(out), N, Cin, Cout, H, W, 1 if relu else 0, ws.data_ptr(), need,
+                         _stream()), "conv3x3")
+    return out
+
+
 def StereoJoin(input_L, input_R, output_L, output_R):
     """adcensus.StereoJoin(input_L, input_R, output_L, output_R) -- adcensus.cu:1479-1498."""
     _chk(input_L, input_R, output_L, output_R)

@@ -39,6 +39,9 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
                      int direction, hipStream_t st);
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
+size_t conv3x3_workspace_bytes(int Cin, int Cout);
+int conv3x3(const float *in, const float *w, const float *bias, float *out, int N, int Cin, int Cout, int H, int W, int relu,
+            void *workspace, hipStream_t st);
 size_t fc_workspace_bytes(int C, int n_hidden, int H, int W);
 int fc_stack(const float *featL, const float *featR, int C, int H, int W, int D, const float *const *weights,
              const float *const *biases, int n_layers, float *volL, float *volR, void *workspace, hipStream_t st);
@@ -469,6 +472,25 @@ int mc_fc_stack(const float *featL, const float *featR, int C, int H, int W, int
 	MC_REQUIRE((uintptr_t)workspace % 16 == 0, "mc_fc_stack: workspace must be 16-byte aligned");
 	MC_REQUIRE((int64_t)((H + 7) / 8) * ((W + 95) / 96) * D * 8 < ((int64_t)1 << 31), "mc_fc_stack: problem too large for one launch");
 	return fc_stack(featL, featR, C, H, W, D, weights, biases, n_layers, volL, volR, workspace, as_stream(stream));
+}
+
+size_t mc_conv3x3_workspace_bytes(int Cin, int Cout)
+{
+	if (Cin < 1 || Cout < 1 || Cout > 128) return 0;
+	return conv3x3_workspace_bytes(Cin, Cout);
+}
+
+int mc_conv3x3(const float *in, const float *weight, const float *bias, float *out, int N, int Cin, int Cout, int H, int W,
+               int relu, void *workspace, size_t workspace_bytes, void *stream)
+{
+	MC_REQUIRE(in && weight && bias && out && workspace && in != out, "mc_conv3x3: bad pointers");
+	MC_REQUIRE(N >= 1 && Cin >= 1 && Cout >= 1 && dims_ok(1, H, W), "mc_conv3x3: bad dims");
+	MC_REQUIRE(Cout <= 128, "mc_conv3x3: Cout=%d exceeds 128 (the nets of main.lua:73-75, 120-122 use 64 and 112)", Cout);
+	MC_REQUIRE(N <= 65535 && (H + 3) / 4 <= 65535, "mc_conv3x3: problem too large for one launch");
+	MC_REQUIRE(workspace_bytes >= conv3x3_workspace_bytes(Cin, Cout), "mc_conv3x3: workspace %zu < %zu bytes", workspace_bytes,
+	           conv3x3_workspace_bytes(Cin, Cout));
+	MC_REQUIRE((uintptr_t)workspace % 16 == 0, "mc_conv3x3: workspace must be 16-byte aligned");
+	return conv3x3(in, weight, bias, out, N, Cin, Cout, H, W, relu, workspace, as_stream(stream));
 }
 
 int mc_fix_border(float *vol, int D, int H, int W, int n, int direction, void *stream)

@@ -131,11 +131,11 @@ def load_fc(net_fname, dataset):
 def features_slow(x_batch, layers):
     """forward_free(net_te, x_batch) for arch slow (main.lua:681-686): l1 x [3x3 conv, pad 1, ReLU]."""
     import torch
-    import torch.nn.functional as F
-    h = x_batch
+    from . import adcensus
+    h = x_batch.contiguous()
     for w, b in layers:
-        h = F.relu(F.conv2d(h, torch.from_numpy(w).to(h.device), torch.from_numpy(b).to(h.device), padding=1))
-    return h.contiguous()
+        h = adcensus.conv3x3(h, torch.from_numpy(w).to(h.device), torch.from_numpy(b).to(h.device), relu=True)
+    return h
 
 
 def raw_volumes_slow(feat, fc_layers, disp_max, border_n):
@@ -153,14 +153,10 @@ def raw_volumes_slow(feat, fc_layers, disp_max, border_n):
 def features_fast(x_batch, layers):
     """forward_free(net_te, x_batch) for arch fast (main.lua:945): convs (pad 1) + ReLU between, then Normalize2."""
     import torch
-    import torch.nn.functional as F
     from . import adcensus
-    h = x_batch
+    h = x_batch.contiguous()
     for i, (w, b) in enumerate(layers):
-        h = F.conv2d(h, torch.from_numpy(w).to(h.device), torch.from_numpy(b).to(h.device), padding=1)
-        if i < len(layers) - 1:
-            h = F.relu(h)
-    h = h.contiguous()
+        h = adcensus.conv3x3(h, torch.from_numpy(w).to(h.device), torch.from_numpy(b).to(h.device), relu=i < len(layers) - 1)
     norm = torch.empty((h.shape[0], 1) + tuple(h.shape[2:]), dtype=torch.float32, device=h.device)
     out = torch.empty_like(h)
     adcensus.Normalize_forward(h, norm, out)   # Normalize2.lua:8-13 -> adcensus.cu:1310-1333
