@@ -14,8 +14,9 @@ code becomes error(mc_last_error()), where the reference calls luaL_error after
 cudaPeekAtLastError (adcensus.cu:31-36).  All launches go to the NULL stream, which is the
 stream the reference's kernels and cutorch's default stream use.
 
-NOTE: LuaJIT/Torch7 are not available in the build image of this repository, so this file is
-exercised only by review; the identical C ABI is driven from Python ctypes in tests/.
+NOTE: LuaJIT/Torch7 are not available in the build image of this repository, so this file cannot be
+executed there; tests/test_lua_shim.py checks its ffi.cdef block, ABI constant and mc_params layout
+against include/mc_adcensus.h, and the identical C ABI is driven from Python ctypes in tests/.
 ]]
 local ffi = require 'ffi'
 
