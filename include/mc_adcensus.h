@@ -265,13 +265,6 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
                    int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
                    int rb, int nt, int d0, int nd, void *stream);
 
-/* EXPERIMENT (deferred-queue cbca kernel): classification bytes, and pack + classify + `iters` iterations
- * vol_in -> ... -> vol_out (tmp is the ping-pong partner; iters odd: result in vol_out). */
-size_t mc_cbca_class_bytes(int D, int H, int W);
-int mc_cbca_dq(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
-               int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
-               void *cls, size_t cls_bytes, int rb, int nt, void *stream);
-
 /* (H,W,D)<->(D,H,W) transpose with the cache policy forced (nt as above); scale multiplies every element. */
 int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, int64_t ldin, int64_t ldout,
                      float scale, int nt, void *stream);

@@ -111,25 +111,6 @@ def cbca_cfg(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, d0=0, nd=0):
                              int(rb), int(nt), int(d0), int(nd), _stream()), "cbca_cfg")
 
 
-_cls_cache = {}
-
-
-def cbca_dq(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1):
-    """EXPERIMENT hook (mc_cbca_dq): pack + classify + one iteration of the deferred-queue kernel."""
-    _chk(x0c, x1c, vol_in, vol_out)
-    D, H, W = vol_out.shape[-3:]
-    need = lib.mc_cbca_scratch_bytes(H, W)
-    scratch = _scratch_for(vol_out.device, need)
-    cb = lib.mc_cbca_class_bytes(D, H, W)
-    key = (str(vol_out.device), cb)
-    if key not in _cls_cache:
-        _cls_cache.clear()
-        _cls_cache[key] = torch.empty(cb, dtype=torch.uint8, device=vol_out.device)
-    cls = _cls_cache[key]
-    check(lib.mc_cbca_dq(_p(x0c), _p(x1c), _p(vol_in), _p(vol_out), D, H, W, int(direction), scratch.data_ptr(), need,
-                         cls.data_ptr(), cb, int(rb), int(nt), _stream()), "cbca_dq")
-
-
 def transpose_cfg(inp, out, rows, cols, ldin, ldout, scale=1.0, nt=-1):
     """Test hook (mc_transpose_cfg): the layout kernel with its cache policy forced."""
     _chk(inp, out)

@@ -37,10 +37,6 @@ size_t cbca_scratch_bytes(int H, int W);
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st);
 int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
                      int direction, hipStream_t st);
-size_t cbca_class_bytes(int D, int H, int W);
-int cbca_classify(const void *packed, void *cls, int D, int H, int W, int direction, hipStream_t st);
-int cbca_dq(const void *packed, const void *cls, const float *vin, float *vout, int D, int H, int W, int direction,
-            hipStream_t st, const CbcaCfg &cfg);
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
 size_t conv3x3_workspace_bytes(int Cin, int Cout);
@@ -569,27 +565,6 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg);
 	if (rc) return rc;
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
-}
-
-size_t mc_cbca_class_bytes(int D, int H, int W) { return cbca_class_bytes(D, H, W); }
-
-int mc_cbca_dq(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
-               void *scratch, size_t scratch_bytes, void *cls, size_t cls_bytes, int rb, int nt, void *stream)
-{
-	MC_REQUIRE(x0c && x1c && vol_in && vol_out && scratch && cls, "mc_cbca_dq: null pointer");
-	MC_REQUIRE(vol_in != vol_out, "mc_cbca_dq: in-place aggregation is not supported");
-	MC_REQUIRE(dims_ok(D, H, W) && D <= 65535 * 8, "mc_cbca_dq: bad dims");
-	MC_REQUIRE(direction == -1 || direction == 1, "mc_cbca_dq: direction must be -1 or 1");
-	MC_REQUIRE(scratch_bytes >= cbca_scratch_bytes(H, W) && cls_bytes >= cbca_class_bytes(D, H, W), "mc_cbca_dq: scratch too small");
-	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_dq: image too large for 32-bit plane offsets");
-	hipStream_t st = as_stream(stream);
-	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
-	if (rc) return rc;
-	rc = cbca_classify(scratch, cls, D, H, W, direction, st);
-	if (rc) return rc;
-	CbcaCfg cfg;
-	cfg.rb = rb; cfg.nt = nt;
-	return cbca_dq(scratch, cls, vol_in, vol_out, D, H, W, direction, st, cfg);
 }
 
 int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, int64_t ldin, int64_t ldout, float scale_, int nt,
