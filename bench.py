@@ -187,7 +187,37 @@ def stage_times(step, reps):
     return acc
 
 
-def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step):
+_COPY_RATE = {}
+
+
+def copy_rate(device, nbytes):
+    """The box's device-to-device copy rate for a working set of the workload's size ('measure achievable
+    with a device-copy kernel on the box and report against both'): read + written bytes per second of
+    dst.copy_(src) over two buffers of nbytes each, best of 10 after 3 warm-ups.  Boxes of the pool differ by up to
+    15 %, and buffers that fit the 256 MB Infinity Cache copy faster than HBM streams."""
+    import torch
+    key = (str(device), int(nbytes))
+    if key not in _COPY_RATE:
+        n = max(int(nbytes) // 4, 1 << 20)
+        src = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        best = float("inf")
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(src)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        _COPY_RATE[key] = 2.0 * n * 4 / (best * 1e-3) / 1e9
+        del src, dst
+        torch.cuda.empty_cache()
+    return _COPY_RATE[key]
+
+
+def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None):
     ab = algorithmic_bytes(prm, H, W, D, max(C, 0))
     nl = launches_per_step(prm, max(C, 0))
     traffic_all = {}
@@ -204,11 +234,17 @@ def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step):
     if dom is None:
         return None
     achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9
-    return dict(bound="hbm", kernel=KERNEL_NAMES[dom], picked_by="largest measured stage time", achieved=round(achieved, 1),
-                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic_all.get(dom),
-                launches_per_step=nl[dom], algorithmic_bytes_per_launch=round(ab[dom] / nl[dom]),
-                avg_launch_ms=round(acc[dom] / nl[dom], 4), kernels=kernels,
-                pipeline_frac=round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    rec = dict(bound="hbm", kernel=KERNEL_NAMES[dom], picked_by="largest measured stage time", achieved=round(achieved, 1),
+               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic_all.get(dom),
+               launches_per_step=nl[dom], algorithmic_bytes_per_launch=round(ab[dom] / nl[dom]),
+               avg_launch_ms=round(acc[dom] / nl[dom], 4), kernels=kernels,
+               pipeline_frac=round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    if device is not None:  # the same figures against what a plain copy of one volume reaches on THIS box
+        cr = copy_rate(device, 4 * D * H * W)
+        rec["box_copy"] = dict(GBs=round(cr, 1), working_set_bytes=2 * 4 * D * H * W, frac_of_peak=round(cr / HBM_PEAK_GBS, 4),
+                               achieved_over_copy=round(achieved / cr, 4),
+                               note="dst.copy_(src) over two buffers of one volume each, best of 10")
+    return rec
 
 
 def north_star_record(device, steps=5):
@@ -249,10 +285,13 @@ def north_star_record(device, steps=5):
                                frac_of_hbm_peak=round(budget / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                frac_incl_layout=round(budget / ((sweep_ms + layout_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                target=0.70),
-               roofline=roofline_record("mb_slow", prm, H, W, D, C, acc, ms),
+               roofline=roofline_record("mb_slow", prm, H, W, D, C, acc, ms, device),
                verify=verify_against_reference(cfg, xb, kw, prm, D, ws, "mb_slow"))
     del ws, xb, kw
     torch.cuda.empty_cache()
+    cr = copy_rate(device, V)   # what a plain copy of one volume reaches on this box
+    rec["per_volume"]["box_copy_GBs"] = round(cr, 1)
+    rec["per_volume"]["sweep_over_box_copy"] = round(budget / (sweep_ms * 1e-3) / 1e9 / cr, 4)
     return rec
 
 
@@ -414,7 +453,7 @@ def main():
                 acc["fc_stack"] = acc.get("fc_stack", 0.0) + e0.elapsed_time(e1) / reps
         acc.update(stage_times(step, reps))
         stage = {k: round(v, 4) for k, v in acc.items()}
-        roof = roofline_record(args.config, prm, H, W, D, C, acc, ms_per_step)
+        roof = roofline_record(args.config, prm, H, W, D, C, acc, ms_per_step, device)
 
     if rank == 0 and fc_ws is not None and roof is not None:
         # the accurate net's dominant kernel is the FC stack: a dense fp32 GEMM chain on the matrix cores
