@@ -206,11 +206,12 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 	// operand of the tile starting at pixel p0 (lane part: pixel nl of the tile, channel parity kh); outside the image: 0
 	auto load_tile = [&](float (&v)[KSTEPS], const __amdgpu_buffer_rsrc_t &r, int p0, bool negate) {
 		const int px = p0 + nl;
+		// the channel offset rides in the vector offset, which the buffer range check covers (the scalar offset is not
+		// checked): channels c >= C lie beyond feat_bytes and read as 0 without a per-channel select
 		const unsigned vo = (px >= 0 && px < W) ? (unsigned)((int64_t)kh * HW + px) * 4u : OOBF;
 #pragma unroll
 		for (int kk = 0; kk < KSTEPS; ++kk) {
-			const int c = 2 * kk + kh;
-			const float t = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, c < C ? vo : OOBF, kk * pair_bytes, 0));
+			const float t = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo + (unsigned)kk * pair_bytes, 0, 0));
 			v[kk] = negate ? -t : t;
 		}
 	};
@@ -313,13 +314,14 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 			if (J >= 0 && J < nJ) do_tile(t, J, part, 32 * T);
 		}
 	};
+	// The prefetch of the next partner tile is issued UNCONDITIONALLY (past the last step it fetches a tile that is never
+	// multiplied): vmcnt counts in order, and a conditional batch of 32 loads makes the compiler wait, before every
+	// MFMA of the step, as if the batch had not been issued -- i.e. for the loads it has just sent.
 	for (int s = 0; s < nsteps; s += 2) {
-		if (s + 1 < nsteps) load_partner(pb, partner_of(s + 1));
+		load_partner(pb, partner_of(s + 1));
 		do_step(s, pa);
-		if (s + 1 < nsteps) {
-			if (s + 2 < nsteps) load_partner(pa, partner_of(s + 2));
-			do_step(s + 1, pb);
-		}
+		load_partner(pa, partner_of(s + 2));
+		if (s + 1 < nsteps) do_step(s + 1, pb);
 	}
 }
 
