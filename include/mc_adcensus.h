@@ -37,7 +37,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define MC_ABI_VERSION 3
+#define MC_ABI_VERSION 4
 #define MC_EINVAL (-22)
 #define MC_SGM_MAX_D 512   /* reference: __shared__ float[400], adcensus.cu:574 */
 #define MC_JOIN_MAX_C 128  /* reference: float L_cache[128], adcensus.cu:1460-1461 */
@@ -258,12 +258,14 @@ int mc_predict_timed(const mc_params *p, const float *x0, const float *x1,
 
 /* ---- test / bench hooks (not part of the reference's surface) ---------------- */
 
-/* mc_cbca_ws with the launch geometry forced instead of derived from the problem size: rows per strip `rb` (0 = auto),
+/* mc_cbca_ws with the launch configuration forced instead of derived from the problem: rows per strip `rb` (0 = auto),
  * cache policy `nt` (-1 = auto, 0 = default policy, 1 = non-temporal volume accesses), planes [d0, d0+nd) only
- * (nd = 0: all).  Lets small-shape parity tests reach the instantiations the benchmarked sizes select. */
+ * (nd = 0: all), kernel `form` (0 = the one mc_cbca_ws takes, 1 = strip kernel, 2 = window kernel -- the one mc_predict
+ * takes for L1 <= 5; it requires every arm <= 4, i.e. arms from mc_cross with L1 <= 5).  Lets small-shape parity tests
+ * reach the instantiations the benchmarked sizes and parameter sets select. */
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
                    int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
-                   int rb, int nt, int d0, int nd, void *stream);
+                   int rb, int nt, int d0, int nd, int form, void *stream);
 
 /* (H,W,D)<->(D,H,W) transpose with the cache policy forced (nt as above); scale multiplies every element. */
 int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, int64_t ldin, int64_t ldout,

@@ -70,7 +70,7 @@ def _load():
         "mc_predict": [C.POINTER(McParams), vp, vp, vp, vp, i, vp, vp, i, i, i, vp, sz, vp, vp, vp, vp, vp, vp],
         "mc_predict_timed": [C.POINTER(McParams), vp, vp, vp, vp, i, vp, vp, i, i, i, vp, sz, vp, vp,
                              C.POINTER(C.c_float)],
-        "mc_cbca_ws_cfg": [vp, vp, vp, vp, i, i, i, i, vp, sz, i, i, i, i, vp],
+        "mc_cbca_ws_cfg": [vp, vp, vp, vp, i, i, i, i, vp, sz, i, i, i, i, i, vp],
         "mc_transpose_cfg": [vp, vp, i64, i64, i64, i64, f, i, vp],
     }
     for name, argtypes in sig.items():
@@ -79,7 +79,7 @@ def _load():
         if name not in ("mc_sgm2_tmp_bytes", "mc_cbca_scratch_bytes", "mc_census_scratch_bytes",
                         "mc_fc_stack_workspace_bytes", "mc_conv3x3_workspace_bytes"):
             fn.restype = C.c_int
-    if lib.mc_version() != 3:
+    if lib.mc_version() != 4:
         raise ImportError("mc-cnn_amd: ABI version mismatch")
     return lib
 

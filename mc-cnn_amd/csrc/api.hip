@@ -545,7 +545,7 @@ int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *v
 }
 
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
-                   void *scratch, size_t scratch_bytes, int rb, int nt, int d0, int nd, void *stream)
+                   void *scratch, size_t scratch_bytes, int rb, int nt, int d0, int nd, int form, void *stream)
 {
 	MC_REQUIRE(x0c && x1c && vol_in && vol_out && scratch, "mc_cbca_ws_cfg: null pointer");
 	MC_REQUIRE(vol_in != vol_out, "mc_cbca_ws_cfg: in-place aggregation is not supported");
@@ -555,13 +555,13 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
 	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws_cfg: image too large for 32-bit plane offsets");
-	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1, "mc_cbca_ws_cfg: bad rb / nt");
+	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 2, "mc_cbca_ws_cfg: bad rb / nt / form");
 	MC_REQUIRE(d0 >= 0 && nd >= 0 && d0 + nd <= D, "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
 	CbcaCfg cfg;
-	cfg.rb = rb; cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd;
+	cfg.rb = rb; cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd; cfg.form = form;
 	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg);
 	if (rc) return rc;
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);

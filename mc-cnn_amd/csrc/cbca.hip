@@ -6,6 +6,7 @@
 // are bit-identical.  No separable / prefix-sum shortcut is taken on this path.
 #include "cbca_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace mc {
 
@@ -368,6 +369,197 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 }
 
 
+// =====================================================================================================
+// cbca: window form for short arms (L1 <= 5), every lane walks its own supports
+// =====================================================================================================
+// Real scenes under the KITTI thresholds (L1 = 5, tau1 = 0.13) are the opposite regime of the strip kernel's: 90 % of the
+// outputs have a support larger than the minimal 3x3 and almost half of the arms sit at the L1-1 = 4 limit (measured on
+// the reference's sample pair; tests/util.natural_pair reproduces the statistics) -- about 36 additions per voxel in a
+// fixed order, compute-bound.  The strip kernel's compaction list then holds every output of the row and its general
+// loop runs from global memory: 6.5 ms per launch at 370x1226x228 against 0.7 ms on a textured pair.
+// Here a wave owns a plane, a strip of 256 staged columns (248 outputs, +-4 halo) and RB rows; a ring of 9 rows (values +
+// nibble-packed minimum arm lengths) covers every support of the output row 4 rows behind the newest one.  A lane owns
+// four adjacent outputs.  Per support row it reads its 12-column window once (3 x ds_read_b128) and, per output, turns the
+// row's (left, right) into a 9-bit run mask (v_bfm); each of the 9 taps is then  sum += bit ? value : -0.0f  as
+// v_bfe_i32 + v_bfi/bitop3 + v_add_f32 -- x + (-0.0f) == x exactly and a value that is not selected is never an operand,
+// so the chain of additions is the reference's (rows ascending, x ascending, one accumulator from +0.0) whatever the
+// unselected columns hold (NaN triangle included).  The row loop runs over the wave's largest up / down arm and the
+// 5-tap form is used on rows where no lane reaches beyond +-2, so textured areas cost a 3 x 5 window.
+constexpr int CW_STEP = 248;   // output columns per strip (frame columns 4 .. 251)
+constexpr int CW_ARM = 4;      // largest arm the window covers
+constexpr int CW_RING = 2 * CW_ARM + 1;
+constexpr int CW_VPITCH = CS_COLS + 8;   // 4 columns of padding on either side: the outermost lanes' windows stay inside the row
+constexpr int CW_WAVES = 2;    // waves per block (each has its own ring)
+
+template <bool NT>
+__global__ void __launch_bounds__(64 * CW_WAVES) cbca_window_kernel(const CbcaArgs A)
+{
+	constexpr int VOL_AUX = NT ? 2 : 0;
+	__shared__ __attribute__((aligned(16))) float Vring[CW_WAVES][CW_RING][CW_VPITCH];
+	__shared__ __attribute__((aligned(16))) unsigned short Mring[CW_WAVES][CW_RING][CS_COLS];
+	if (A.overflow && *A.overflow) return;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int H = A.H, W = A.W, direction = A.direction;
+	const int HWi = H * W;
+	// wave -> (region, d) as in the strip kernel: the waves of a block take consecutive disparities of one region, the
+	// blocks of an XCD walk all disparity groups of a region before the next one
+	const int dgroups = (A.nd + CW_WAVES - 1) / CW_WAVES;
+	const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
+	const int region = (kb / dgroups) * 8 + xcd;
+	const int d = A.d0 + (kb % dgroups) * CW_WAVES + wv;
+	if (region >= A.gx * A.gy || d >= A.d0 + A.nd) return;
+	const int cx = region % A.gx, cy = region / A.gx;
+	const int sh = d * direction;
+	const int xs0 = cx * CW_STEP - CW_ARM;        // image column of frame column 0 (wave-uniform)
+	const int xs = xs0 + 4 * lane;                // image column of this lane's four columns = its four outputs
+	const int y0 = cy * A.rb, y1 = min(H, y0 + A.rb);
+	const int ra = y0 - CW_ARM;                   // first staged row
+	const int plane_bytes = HWi * 4;
+	const cb_u32 OOB = 0x80000000u;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
+	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
+	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
+	const bool full_in = xs >= 0 && xs + 3 < W;
+	const bool has_out = lane >= 1 && lane <= 62;
+	const bool full_out = has_out && xs + 3 < W;
+	const bool any_out = has_out && xs < W;
+	bool exists[4], inr[4];   // output column exists / its shifted partner is inside the image (adcensus.cu:353-354)
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int x = xs + j;
+		exists[j] = has_out && x < W;
+		inr[j] = x + sh >= 0 && x + sh < W;
+	}
+	float *__restrict__ Vw = &Vring[wv][0][0];
+	unsigned short *__restrict__ Mw = &Mring[wv][0][0];
+
+	struct Stage { cb_u4 v, a, b; };
+	auto fetch = [&](Stage &st, int r) {  // row r of the plane and of the two length maps -> registers (rows outside the image: zeros)
+		const bool rok = r >= 0 && r < H;
+		const int base = r * W + xs;
+		if (full_in) {
+			st.v = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)base * 4u : OOB, 0, VOL_AUX);
+		} else {
+			cb_u32 t[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_raw_buffer_load_b32(rv, (rok && xs + k >= 0 && xs + k < W) ? (cb_u32)(base + k) * 4u : OOB, 0, 0);
+			st.v = cb_u4{t[0], t[1], t[2], t[3]};
+		}
+		st.a = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
+		st.b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
+	};
+	// lengths (left, right, up, down) as four nibbles: every arm this kernel is launched for is <= CW_ARM
+	auto nib = [](cb_u32 m) -> cb_u32 { return (m & 0xfu) | ((m >> 4) & 0xf0u) | ((m >> 8) & 0xf00u) | ((m >> 12) & 0xf000u); };
+	auto commit = [&](const Stage &st, int slot) {
+		*(cb_u4 *)(Vw + slot * CW_VPITCH + 4 + 4 * lane) = st.v;
+		const cb_u32 m0 = nib(bytemin4(st.a.x, st.b.x)), m1 = nib(bytemin4(st.a.y, st.b.y));
+		const cb_u32 m2 = nib(bytemin4(st.a.z, st.b.z)), m3 = nib(bytemin4(st.a.w, st.b.w));
+		*(cb_u2 *)(Mw + slot * CS_COLS + 4 * lane) = cb_u2{m0 | (m1 << 16), m2 | (m3 << 16)};
+	};
+
+	auto output = [&](int yo, int rs) {  // rs = ring slot of the newest row yo + CW_ARM
+		// own lengths: the up / down arms bound the rows, negative = this output takes no taps at all
+		int s0 = rs + (CW_RING - CW_ARM);
+		s0 = s0 >= CW_RING ? s0 - CW_RING : s0;
+		const cb_u2 mo = *(const cb_u2 *)(Mw + s0 * CS_COLS + 4 * lane);
+		const cb_u32 mown[4] = {mo.x & 0xffffu, mo.x >> 16, mo.y & 0xffffu, mo.y >> 16};
+		int up[4], dn[4], umax = 0, dmax = 0;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const bool take = exists[j] && inr[j];
+			up[j] = take ? (int)((mown[j] >> 8) & 0xfu) : -1;
+			dn[j] = take ? (int)(mown[j] >> 12) : -1;
+			umax = max(umax, up[j]);
+			dmax = max(dmax, dn[j]);
+		}
+		int Uw = 0, Dw = 0;   // the wave's largest arms (values 0 .. 4): three ballots each
+#pragma unroll
+		for (int t = 1; t <= CW_ARM; ++t) {
+			Uw = __any(umax >= t) ? t : Uw;
+			Dw = __any(dmax >= t) ? t : Dw;
+		}
+		float sum[4], own[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+		int cnt[4] = {0, 0, 0, 0};
+		bool started = false;
+		for (int rel = -Uw; rel <= Dw; ++rel) {
+			int sl = rs + (CW_RING - CW_ARM) + rel;          // slot of row yo + rel
+			sl = sl >= CW_RING ? sl - CW_RING : sl;
+			sl = sl < 0 ? sl + CW_RING : sl;
+			const float *__restrict__ vr = Vw + sl * CW_VPITCH + 4 * lane;   // frame column 4*lane - 4
+			const cb_f4 q0 = *(const cb_f4 *)vr, q1 = *(const cb_f4 *)(vr + 4), q2 = *(const cb_f4 *)(vr + 8);
+			const float v[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+			const cb_u2 mr = *(const cb_u2 *)(Mw + sl * CS_COLS + 4 * lane);
+			const cb_u32 mrow[4] = {mr.x & 0xffffu, mr.x >> 16, mr.y & 0xffffu, mr.y >> 16};
+			if (rel == 0) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) own[j] = v[4 + j];
+			}
+			const int arel = rel < 0 ? -rel : rel;
+			cb_u32 mask[4], anywide = 0;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const int need = rel < 0 ? up[j] : dn[j];
+				const cb_u32 l = mrow[j] & 0xfu, r = (mrow[j] >> 4) & 0xfu;
+				const cb_u32 run = ((1u << (l + r + 1u)) - 1u) << (CW_ARM - l);   // bit k <-> column offset k - 4
+				mask[j] = need >= arel ? run : 0u;
+				cnt[j] += __builtin_popcount(mask[j]);
+				anywide |= mask[j];
+			}
+			const bool wide = __any((anywide & 0x183u) != 0);   // a tap at +-3 or +-4 somewhere in the wave
+			auto taps = [&](auto first_k, auto last_k) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+#pragma unroll
+					for (int k = first_k; k <= last_k; ++k) {
+						const cb_u32 keep = (cb_u32)(((int)(mask[j] << (31 - k))) >> 31);   // all ones if the tap is in the run
+						float t;   // keep ? value : -0.0f as ONE bit-field insert (left to itself the compiler shares partial
+						           // and/or terms between taps and ends up with four to five operations per tap)
+						asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(t) : "v"(keep), "v"(v[j + k]), "s"(0x80000000u));
+						if (!started && k == first_k) asm("v_add_f32 %0, 0, %1" : "=v"(sum[j]) : "v"(t));   // from +0.0
+						else sum[j] += t;
+					}
+				}
+			};
+			if (wide) taps(std::integral_constant<int, 0>(), std::integral_constant<int, 8>());
+			else taps(std::integral_constant<int, 2>(), std::integral_constant<int, 6>());
+			started = true;
+		}
+		float res[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) res[j] = inr[j] ? sum[j] / (float)cnt[j] : own[j];   // adcensus.cu:353-354: copied through
+		const int ob = yo * W + xs;
+		if (full_out) {
+			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
+			                                       ro, (cb_u32)ob * 4u, 0, VOL_AUX);
+		} else if (any_out) {
+#pragma unroll
+			for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[j]), ro, xs + j < W ? (cb_u32)(ob + j) * 4u : OOB, 0, 0);
+		}
+	};
+
+	constexpr int PF = 2;
+	Stage st[PF];
+#pragma unroll
+	for (int u = 0; u < PF; ++u) fetch(st[u], ra + u);
+	const int last = y1 - 1 + CW_ARM;
+	int rs = 0;   // ring slot of the row being committed
+	for (int g = ra; g <= last; g += PF) {
+#pragma unroll
+		for (int u = 0; u < PF; ++u) {
+			const int r = g + u;
+			if (r > last) break;
+			commit(st[u], rs);
+			fetch(st[u], r + PF);
+			const int yo = r - CW_ARM;
+			if (yo >= y0 && yo < y1) output(yo, rs);
+			rs = rs + 1 == CW_RING ? 0 : rs + 1;
+		}
+	}
+}
+
 size_t cbca_scratch_bytes(int H, int W) { return (((size_t)2 * H * W + 3 * CS_PAD + 1) * sizeof(uint32_t) + 255) & ~(size_t)255; }
 
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st)
@@ -419,6 +611,18 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(nd, 4) * 4;
 	// non-temporal volume accesses for volumes far larger than the 256 MB Infinity Cache (see cbca_strip_kernel)
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
+	// short arms (L1 <= 5, the KITTI parameter sets): every lane walks its own supports out of a 9-row ring
+	const bool window = cfg.form == 2 || (cfg.form == 0 && max_arm >= 0 && max_arm <= CW_ARM);
+	if (window) {
+		A.gx = (int)cdiv(W, CW_STEP);
+		const int64_t gy_w = cdiv((int64_t)16384, (int64_t)A.gx * nd);
+		A.rb = cfg.rb > 0 ? cfg.rb : (int)std::min<int64_t>(40, std::max<int64_t>(16, cdiv((int64_t)H, gy_w)));
+		A.gy = (int)cdiv(H, A.rb);
+		const int64_t wv = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(nd, CW_WAVES) * CW_WAVES;
+		if (nt) hipLaunchKernelGGL((cbca_window_kernel<true>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, A);
+		else hipLaunchKernelGGL((cbca_window_kernel<false>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, A);
+		return check_launch("cbca_window");
+	}
 	// prefetch 2 rows, ring of 4 rows, 1 row of look-ahead, window form +-2 columns (+-4 measured slower at KITTI and 1000x1500)
 	if (nt) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
 	else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);

@@ -105,3 +105,69 @@ def test_cbca_special_values(mc, oracle):
         mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=rb, nt=nt)
         got = out.cpu().numpy()
         assert same_bits(got, want), diff_report(got, want, "special values rb=%d nt=%d" % (rb, nt))
+
+
+# ---- the window kernel (cbca form 2: what mc_predict takes for L1 <= 5) ---------------------------------------------
+@pytest.mark.parametrize("H,W,D", [(90, 300, 9), (41, 519, 6), (27, 253, 5), (83, 64, 12), (37, 249, 4), (12, 497, 3)])
+@pytest.mark.parametrize("rb", [0, 16, 40])
+@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 5, 0.13), ("random", 5, 0.5), ("blocky", 5, 0.2), ("natural", 5, 0.13),
+                                        ("natural", 3, 0.03), ("blocky", 2, 0.3), ("smooth", 0, 0.0), ("natural", 4, 1.0)])
+def test_cbca_window_kernel(mc, oracle, H, W, D, rb, mk, L1, tau1):
+    """short arms (<= 4): every kind of image, strips with ragged edges, all row-chunk sizes, both cache policies, both
+    directions -- against the oracle, bit for bit"""
+    from util import natural_pair
+    x0, x1 = {"smooth": lambda: smooth_pair(H, W, 8, seed=H), "random": lambda: random_pair(H, W, seed=W),
+              "blocky": lambda: blocky_pair(H, W, seed=D), "natural": lambda: natural_pair(H, W, 8, seed=H + W, sigma=8.0)}[mk]()
+    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
+    vl, vr = raw_volumes(D, H, W, seed=13)
+    for direction, vol in ((-1, vl), (1, vr)):
+        want = oracle.cbca(x0c, x1c, vol, direction)
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=(H + rb) & 1, form=2)
+        got = out.cpu().numpy()
+        assert same_bits(got, want), diff_report(got, want, "window kernel rb=%d dir=%d" % (rb, direction))
+
+
+def test_cbca_window_kernel_special_values(mc, oracle):
+    """zeros, negative zeros, denormals, huge values, infinities and NaNs inside the valid region: a tap that is not in the
+    support is never an operand (an inf / NaN next to a support must not leak into it), a support of nothing but -0.0
+    sums to +0.0"""
+    H, W, D = 40, 260, 6
+    x0, x1 = blocky_pair(H, W, seed=8)
+    x0c, x1c = oracle.cross(x0, 5, 0.2), oracle.cross(x1, 5, 0.2)
+    vl, _ = raw_volumes(D, H, W, seed=3)
+    rng = np.random.default_rng(1)
+    vl[0, :, 20:] = 0.0
+    vl[1, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-42)
+    vl[2, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-30)
+    vl[3, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(3e38)
+    for k in range(40):
+        vl[4, rng.integers(0, H), rng.integers(20, W)] = np.inf if k & 1 else np.nan
+    vl[5, :, 20:] = -rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-38)
+    vl[5, 25:, 20:] = -0.0
+    with np.errstate(all="ignore"):
+        want = oracle.cbca(x0c, x1c, vl, -1)
+    for rb, nt in ((0, -1), (25, 1)):
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=rb, nt=nt, form=2)
+        got = out.cpu().numpy()
+        assert same_bits(got, want), diff_report(got, want, "window kernel special values rb=%d nt=%d" % (rb, nt))
+
+
+def test_cbca_forms_agree_on_a_realistic_pair(mc):
+    """strip kernel, window kernel and the one-thread-per-voxel kernel on a pair with real-scene arm statistics"""
+    from util import natural_pair
+    H, W, D = 120, 700, 20
+    x0, x1 = natural_pair(H, W, D, seed=5)
+    xb = dev(np.stack([x0, x1]))[:, None]
+    x0c = torch.empty((1, 4, H, W), device="cuda"); x1c = torch.empty_like(x0c)
+    mc.adcensus.cross(xb[0:1], x0c, 5, 0.13); mc.adcensus.cross(xb[1:2], x1c, 5, 0.13)
+    vin = torch.rand((1, D, H, W), device="cuda")
+    outs = []
+    for form in (1, 2):
+        o = torch.full_like(vin, -7.0)
+        mc.adcensus.cbca_cfg(x0c, x1c, vin, o, -1, form=form)
+        outs.append(o.cpu().numpy())
+    o = torch.full_like(vin, -7.0)
+    mc.adcensus.cbca_reference_shaped(x0c, x1c, vin, o, -1)
+    assert same_bits(outs[0], o.cpu().numpy()) and same_bits(outs[1], o.cpu().numpy())

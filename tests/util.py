@@ -25,6 +25,40 @@ def smooth_pair(H, W, D, seed=1234, noise=0.05):
     return normalize_image(left[:, :W]), normalize_image(right[:, :W])
 
 
+def natural_pair(H, W, D, seed=1234, sigma=40.0, tex_frac=0.25, tex_amp=0.35, sensor_noise=0.3, levels_per_std=60.0, clip=1.3):
+    """A pair with the cross-arm statistics of a real 8-bit road scene: large smooth regions, a quarter of the area
+    textured, sensor noise of a fraction of a grey level, rounding to grey levels (neighbouring pixels are often EQUAL),
+    clipped highlights; right = left shifted by a smooth disparity field.
+    Calibrated in the build container against the reference's sample pair (samples/input/kittiL.png / kittiR.png, which
+    do not travel): share of outputs whose support is larger than the minimal 3x3 / share of per-arm minima at the L1-1
+    limit / mean arm, arms combined over both images at d = 0 .. 120:
+                                    real pair                     natural_pair                 smooth_pair
+        cross(L1=5,  tau1=0.13)     0.90 / 0.37-0.48 / 2.3-2.6    0.87-0.89 / 0.40-0.47 / 2.5-2.7    0.20 / 0.00 / 1.03
+        cross(L1=14, tau1=0.02)     0.44-0.50 / 0.02-0.07 / 1.5-2.2    0.48-0.52 / 0.03-0.05 / 1.8-2.2    0.013 / 0 / 1.00
+        cross(L1=5,  tau1=0.03)     0.57-0.60 / 0.12-0.21 / 1.5-1.8    0.48-0.52 / 0.09-0.13 / 1.4-1.5
+    (the Gaussian textures of smooth_pair / random_pair are the regime in which nearly every support is the minimal 3x3)"""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    Wp = W + D
+    base = gaussian_filter(rng.standard_normal((H, Wp)), sigma)
+    base /= base.std()
+    sel = gaussian_filter(rng.standard_normal((H, Wp)), 25.0)
+    tex = (sel > np.quantile(sel, 1 - tex_frac)).astype(np.float64)
+    clean = base + tex * tex_amp * rng.standard_normal((H, Wp))
+    disp = gaussian_filter(rng.random((H, Wp)), 12.0)
+    disp = (disp - disp.min()) / (disp.max() - disp.min() + 1e-12) * 0.8 * (D - 1)
+    xs = np.arange(Wp)[None, :] + disp
+    x0 = np.floor(xs).astype(int).clip(0, Wp - 1)
+    x1 = (x0 + 1).clip(0, Wp - 1)
+    f = xs - np.floor(xs)
+    rows = np.arange(H)[:, None]
+    shifted = clean[rows, x0] * (1 - f) + clean[rows, x1] * f
+
+    def sensor(im):  # noise of a fraction of a grey level, rounding to grey levels, highlights clipped
+        return np.minimum(np.round(im * levels_per_std + sensor_noise * rng.standard_normal(im.shape)), np.round(clip * levels_per_std))
+    return normalize_image(sensor(clean)[:, :W]), normalize_image(sensor(shifted)[:, :W])
+
+
 def random_pair(H, W, seed=0):
     rng = np.random.default_rng(seed)
     return (normalize_image(rng.standard_normal((H, W))), normalize_image(rng.standard_normal((H, W))))
