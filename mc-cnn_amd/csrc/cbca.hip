@@ -370,56 +370,37 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 
 
 // =====================================================================================================
-// cbca: window form -- every lane walks its own supports (real-scene arm statistics)
+// cbca: window form for short arms (L1 <= 5) -- every lane walks its own supports
 // =====================================================================================================
 // Real 8-bit scenes are the opposite regime of the strip kernel's.  Under the KITTI thresholds (L1 = 5, tau1 = 0.13) 90 %
-// of the outputs have a support larger than the minimal 3x3 and almost half of the arms sit at the L1-1 = 4 limit; under
-// the Middlebury ones (L1 = 14, tau1 = 0.02) half of the supports are minimal, 93 % fit a 9x9 window and 4-6 % are flat
-// regions (clipped highlights, grey levels that are EQUAL) with up to 27 x 27 = 729 taps, which carry two thirds of all
-// additions (measured on the reference's sample pair; tests/util.natural_pair reproduces the statistics).  About 40
-// additions per voxel in a fixed order: compute-bound.  The strip kernel's compaction list then holds every output of the
-// row and its general loop runs at the pace of the largest support of each pass, from global memory: 6.2 ms per launch at
-// 370x1226x228 and 56 ms at 1000x1500x256 against 0.7 / 1.0 ms on a Gaussian texture.
+// of the outputs have a support larger than the minimal 3x3 and almost half of the arms sit at the L1-1 = 4 limit
+// (measured on the reference's sample pair; tests/util.natural_pair reproduces the statistics): about 40 additions per
+// voxel in a fixed order, compute-bound.  The strip kernel's compaction list then holds every output of the row and its
+// general loop runs at the pace of the largest support of each pass, from global memory: 6.2 ms per launch at
+// 370x1226x228 against 0.8 ms on a Gaussian texture.
 //
-// Here a wave owns a plane, a strip of 256 staged columns and RB rows, and a lane owns four adjacent outputs.
-//   * Window walk (supports inside +-4 rows x +-4 columns): per support row the lane reads its 12-column window once
-//     (3 x ds_read_b128) and, per output, turns the row's (left, right) into a 9-bit run mask; each of the 9 taps is then
-//     sum += bit ? value : -0.0f  as v_bfe_i32 + v_bfi_b32 + v_add_f32.  x + (-0.0f) == x exactly and a value that is
-//     not selected is never an operand, so the chain of additions is the reference's (rows ascending, x ascending, one
-//     accumulator from +0.0) whatever the unselected columns hold (NaN triangle included).  The row loop runs over the
-//     wave's largest up / down arm and the 5-tap form is used on rows where no lane reaches beyond +-2.
-//   * ARM > 4 (L1 up to 14): the rings cover +-ARM rows and the strip's halo is 16 columns, so that EVERY support lies
-//     inside them; outputs whose support leaves the 9x9 window take a second walk of the same form over +-ARM rows and
-//     27 taps per row (the lane's four outputs share the row's 36-column window).  In flat regions all lanes of a wave
-//     take it together, elsewhere nearly none, so little of it is spent on unselected taps.
-// ARM = 4: rings of 9 rows, halo 4, 248 outputs per strip, two waves per block.  ARM = 13: value ring and (left, right)
-// ring of 27 rows, (up, down) ring of 16 rows, halo 16, 224 outputs per strip, one wave per block (37.8 KB: 4 waves / CU).
-constexpr int CW_WIN = 4;      // the window covers +-4 rows and columns
+// Here a wave owns a plane, a strip of 256 staged columns (248 outputs, +-4 halo) and RB rows; rings of 9 rows (values,
+// nibble-packed minimum arm lengths) cover every support of the output row 4 rows behind the newest one.  A lane owns four
+// adjacent outputs.  Per support row it reads its 12-column window once (3 x ds_read_b128) and, per output, turns the
+// row's (left, right) into a 9-bit run mask; each of the 9 taps is then  sum += bit ? value : -0.0f  as v_bfe_i32 +
+// v_bfi_b32 + v_add_f32.  x + (-0.0f) == x exactly and a value that is not selected is never an operand, so the chain of
+// additions is the reference's (rows ascending, x ascending, one accumulator from +0.0) whatever the unselected columns
+// hold (NaN triangle included).  The row loop runs over the wave's largest up / down arm and the 5-tap form is used on
+// rows where no lane reaches beyond +-2, so textured areas cost a 3 x 5 window.
+// (A version of this kernel for arms up to 13 -- 27-row rings, a second walk over +-13 rows -- is in the history, commit
+// c898b0c: bit-exact, but slower than one thread per voxel on the realistic pair)
+constexpr int CW_ARM = 4;                    // largest arm the window covers
+constexpr int CW_STEP = CS_COLS - 2 * CW_ARM;   // 248 output columns per strip (frame columns 4 .. 251)
+constexpr int CW_RING = 2 * CW_ARM + 1;
+constexpr int CW_VPITCH = CS_COLS + 8;       // 4 columns of padding on either side: the outermost lanes' windows stay inside the row
+constexpr int CW_WAVES = 2;                  // waves per block (each has its own rings)
 
-template <int ARM> struct CwGeom {
-	static constexpr int HALO = ARM <= CW_WIN ? 4 : 16;
-	static constexpr int STEP = CS_COLS - 2 * HALO;      // output columns per strip
-	static constexpr int LANE0 = HALO / 4, LANE1 = 63 - HALO / 4;   // lanes that own outputs
-	static constexpr int RV = 2 * ARM + 1;                // value ring rows
-	static constexpr int RM = 2 * CW_WIN + 1;             // ARM = 4: lengths ring rows (four nibbles per column)
-	static constexpr int RU = 16;                         // ARM > 4: rows of the ring of (up, down) bytes (>= ARM + 1, power of two)
-	static constexpr int WAVES = ARM <= CW_WIN ? 2 : 1;   // waves per block (each has its own rings)
-	static constexpr int VOFF = ARM <= CW_WIN ? 4 : 0;    // halo 4: the outermost lanes' windows need padding columns
-	static constexpr int VPITCH = CS_COLS + 2 * VOFF;
-};
-
-template <int ARM, bool NT>
-__global__ void __launch_bounds__(64 * CwGeom<ARM>::WAVES) cbca_window_kernel(const CbcaArgs A)
+template <bool NT>
+__global__ void __launch_bounds__(64 * CW_WAVES) cbca_window_kernel(const CbcaArgs A)
 {
-	typedef CwGeom<ARM> G;
 	constexpr int VOL_AUX = NT ? 2 : 0;
-	constexpr bool DEEP = ARM > CW_WIN;
-	__shared__ __attribute__((aligned(16))) float Vring[G::WAVES][G::RV][G::VPITCH];
-	// lengths: ARM = 4 one ring of 16-bit (left, right, up, down) nibbles; ARM > 4 a ring of (left | right << 4) bytes as deep
-	// as the value ring and a ring of (up | down << 4) bytes that only has to reach back to the output row
-	__shared__ __attribute__((aligned(16))) unsigned short Mring[DEEP ? 1 : G::WAVES][DEEP ? 1 : G::RM][DEEP ? 4 : CS_COLS];
-	__shared__ __attribute__((aligned(16))) unsigned char LRring[DEEP ? G::WAVES : 1][DEEP ? G::RV : 1][DEEP ? CS_COLS : 4];
-	__shared__ __attribute__((aligned(16))) unsigned char UDring[DEEP ? G::WAVES : 1][DEEP ? G::RU : 1][DEEP ? CS_COLS : 4];
+	__shared__ __attribute__((aligned(16))) float Vring[CW_WAVES][CW_RING][CW_VPITCH];
+	__shared__ __attribute__((aligned(16))) unsigned short Mring[CW_WAVES][CW_RING][CS_COLS];
 	if (A.overflow && *A.overflow) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -427,27 +408,26 @@ __global__ void __launch_bounds__(64 * CwGeom<ARM>::WAVES) cbca_window_kernel(co
 	const int HWi = H * W;
 	// wave -> (region, d) as in the strip kernel: the waves of a block take consecutive disparities of one region, the
 	// blocks of an XCD walk all disparity groups of a region before the next one
-	const int dgroups = (A.nd + G::WAVES - 1) / G::WAVES;
+	const int dgroups = (A.nd + CW_WAVES - 1) / CW_WAVES;
 	const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
 	const int region = (kb / dgroups) * 8 + xcd;
-	const int d = A.d0 + (kb % dgroups) * G::WAVES + wv;
+	const int d = A.d0 + (kb % dgroups) * CW_WAVES + wv;
 	if (region >= A.gx * A.gy || d >= A.d0 + A.nd) return;
 	const int cx = region % A.gx, cy = region / A.gx;
 	const int sh = d * direction;
-	const int xs0 = cx * G::STEP - G::HALO;       // image column of frame column 0 (wave-uniform)
+	const int xs0 = cx * CW_STEP - CW_ARM;        // image column of frame column 0 (wave-uniform)
 	const int xs = xs0 + 4 * lane;                // image column of this lane's four columns = its four outputs
 	const int y0 = cy * A.rb, y1 = min(H, y0 + A.rb);
-	const int ra = y0 - ARM;                      // first staged row
+	const int ra = y0 - CW_ARM;                   // first staged row
 	const int plane_bytes = HWi * 4;
 	const cb_u32 OOB = 0x80000000u;
-	const float *__restrict__ plane_in = A.vin + (size_t)d * HWi;
-	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)plane_in, 0, plane_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
 	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
 	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
 	const bool full_in = xs >= 0 && xs + 3 < W;
-	const bool has_out = lane >= G::LANE0 && lane <= G::LANE1;
+	const bool has_out = lane >= 1 && lane <= 62;
 	const bool full_out = has_out && xs + 3 < W;
 	const bool any_out = has_out && xs < W;
 	bool exists[4], inr[4];   // output column exists / its shifted partner is inside the image (adcensus.cu:353-354)
@@ -458,12 +438,7 @@ __global__ void __launch_bounds__(64 * CwGeom<ARM>::WAVES) cbca_window_kernel(co
 		inr[j] = x + sh >= 0 && x + sh < W;
 	}
 	float *__restrict__ Vw = &Vring[wv][0][0];
-	unsigned short *__restrict__ Mw = &Mring[DEEP ? 0 : wv][0][0];
-	unsigned char *__restrict__ LRw = &LRring[DEEP ? wv : 0][0][0];
-	unsigned char *__restrict__ UDw = &UDring[DEEP ? wv : 0][0][0];
-	// first column of a lane's 12-column window inside a ring row (lanes without outputs read a window that exists)
-	const int wlane = DEEP ? min(max(lane, 1), 62) : lane;
-	const int wcol = G::VOFF + 4 * wlane - 4;
+	unsigned short *__restrict__ Mw = &Mring[wv][0][0];
 
 	struct Stage { cb_u4 v, a, b; };
 	auto fetch = [&](Stage &st, int r) {  // values and lengths of row r -> registers (rows outside the image: zeros)
@@ -480,49 +455,33 @@ __global__ void __launch_bounds__(64 * CwGeom<ARM>::WAVES) cbca_window_kernel(co
 		st.a = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
 		st.b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
 	};
-	// lengths (left, right, up, down) as four nibbles: every arm this kernel is launched for is <= 15
+	// lengths (left, right, up, down) as four nibbles: every arm this kernel is launched for is <= CW_ARM
 	auto nib = [](cb_u32 m) -> cb_u32 { return (m & 0xfu) | ((m >> 4) & 0xf0u) | ((m >> 8) & 0xf00u) | ((m >> 12) & 0xf000u); };
-	auto commit = [&](const Stage &st, int sv, int sm, int r) {
-		*(cb_u4 *)(Vw + sv * G::VPITCH + G::VOFF + 4 * lane) = st.v;
+	auto commit = [&](const Stage &st, int slot) {
+		*(cb_u4 *)(Vw + slot * CW_VPITCH + 4 + 4 * lane) = st.v;
 		const cb_u32 m0 = nib(bytemin4(st.a.x, st.b.x)), m1 = nib(bytemin4(st.a.y, st.b.y));
 		const cb_u32 m2 = nib(bytemin4(st.a.z, st.b.z)), m3 = nib(bytemin4(st.a.w, st.b.w));
-		if (DEEP) {
-			*(cb_u32 *)(LRw + sv * CS_COLS + 4 * lane) = (m0 & 0xffu) | ((m1 & 0xffu) << 8) | ((m2 & 0xffu) << 16) | ((m3 & 0xffu) << 24);
-			*(cb_u32 *)(UDw + (r & (G::RU - 1)) * CS_COLS + 4 * lane) = (m0 >> 8) | (m1 & 0xff00u) | ((m2 & 0xff00u) << 8) | ((m3 & 0xff00u) << 16);
-		} else {
-			*(cb_u2 *)(Mw + sm * CS_COLS + 4 * lane) = cb_u2{m0 | (m1 << 16), m2 | (m3 << 16)};
-		}
+		*(cb_u2 *)(Mw + slot * CS_COLS + 4 * lane) = cb_u2{m0 | (m1 << 16), m2 | (m3 << 16)};
 	};
 
-	// output row yo = (newest value row) - ARM = (newest lengths row) - 4; sv / sm = ring slots of those newest rows
-	auto output = [&](int yo, int sv, int sm) {  // sm: ARM = 4 only
-		cb_u32 ud[4];   // (up | down << 4) of the own row
-		if (DEEP) {
-			const cb_u32 w = *(const cb_u32 *)(UDw + (yo & (G::RU - 1)) * CS_COLS + 4 * lane);
-			ud[0] = w & 0xffu; ud[1] = (w >> 8) & 0xffu; ud[2] = (w >> 16) & 0xffu; ud[3] = w >> 24;
-		} else {
-			int s0 = sm + (G::RM - CW_WIN);
-			s0 = s0 >= G::RM ? s0 - G::RM : s0;
-			const cb_u2 mo = *(const cb_u2 *)(Mw + s0 * CS_COLS + 4 * lane);
-			ud[0] = (mo.x >> 8) & 0xffu; ud[1] = mo.x >> 24; ud[2] = (mo.y >> 8) & 0xffu; ud[3] = mo.y >> 24;
-		}
+	auto output = [&](int yo, int rs) {  // rs = ring slot of the newest row yo + CW_ARM
+		// own lengths: the up / down arms bound the rows, negative = this output takes no taps at all
+		int s0 = rs + (CW_RING - CW_ARM);
+		s0 = s0 >= CW_RING ? s0 - CW_RING : s0;
+		const cb_u2 mo = *(const cb_u2 *)(Mw + s0 * CS_COLS + 4 * lane);
+		const cb_u32 ud[4] = {(mo.x >> 8) & 0xffu, mo.x >> 24, (mo.y >> 8) & 0xffu, mo.y >> 24};   // up | down << 4
 		int up[4], dn[4], umax = 0, dmax = 0;
-		int ubig = 0, dbig = 0;   // DEEP: the largest arms among this lane's outputs that leave the window
-		bool big[4] = {false, false, false, false};   // DEEP: the support leaves the window, the lane walks it with the general loop
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const bool take = exists[j] && inr[j];
-			const int u = (int)(ud[j] & 0xfu), dd = (int)(ud[j] >> 4);
-			if (DEEP) big[j] = take && (u > CW_WIN || dd > CW_WIN);
-			const bool win = take && !big[j];
-			up[j] = win ? u : -1;      // negative: this output takes no taps in the window walk
-			dn[j] = win ? dd : -1;
+			up[j] = take ? (int)(ud[j] & 0xfu) : -1;
+			dn[j] = take ? (int)(ud[j] >> 4) : -1;
 			umax = max(umax, up[j]);
 			dmax = max(dmax, dn[j]);
 		}
-		int Uw = 0, Dw = 0;   // the wave's largest arms inside the window (0 .. 4): ballots
+		int Uw = 0, Dw = 0;   // the wave's largest arms (0 .. 4): ballots
 #pragma unroll
-		for (int t = 1; t <= CW_WIN; ++t) {
+		for (int t = 1; t <= CW_ARM; ++t) {
 			Uw = __any(umax >= t) ? t : Uw;
 			Dw = __any(dmax >= t) ? t : Dw;
 		}
@@ -533,22 +492,13 @@ __global__ void __launch_bounds__(64 * CwGeom<ARM>::WAVES) cbca_window_kernel(co
 		for (int j = 0; j < 4; ++j) asm("v_mov_b32 %0, 0" : "=v"(sum[j]));
 		int cnt[4] = {0, 0, 0, 0};
 		for (int rel = -Uw; rel <= Dw; ++rel) {
-			int sl = sv - ARM + rel;                          // value slot of row yo + rel
-			sl = sl < 0 ? sl + G::RV : sl;
-			const float *__restrict__ vr = Vw + sl * G::VPITCH + wcol;   // frame column 4*lane - 4
+			int sl = rs - CW_ARM + rel;                       // slot of row yo + rel
+			sl = sl < 0 ? sl + CW_RING : sl;
+			const float *__restrict__ vr = Vw + sl * CW_VPITCH + 4 * lane;   // frame column 4*lane - 4
 			const cb_f4 q0 = *(const cb_f4 *)vr, q1 = *(const cb_f4 *)(vr + 4), q2 = *(const cb_f4 *)(vr + 8);
 			const float v[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-			cb_u32 mrow[4];   // low byte: left | right << 4 of row yo + rel
-			if (DEEP) {
-				const cb_u32 w = *(const cb_u32 *)(LRw + sl * CS_COLS + 4 * lane);
-				mrow[0] = w; mrow[1] = w >> 8; mrow[2] = w >> 16; mrow[3] = w >> 24;
-			} else {
-				int ml = sm + (G::RM - CW_WIN) + rel;         // lengths slot of row yo + rel
-				ml = ml >= G::RM ? ml - G::RM : ml;
-				ml = ml < 0 ? ml + G::RM : ml;
-				const cb_u2 mr = *(const cb_u2 *)(Mw + ml * CS_COLS + 4 * lane);
-				mrow[0] = mr.x; mrow[1] = mr.x >> 16; mrow[2] = mr.y; mrow[3] = mr.y >> 16;
-			}
+			const cb_u2 mr = *(const cb_u2 *)(Mw + sl * CS_COLS + 4 * lane);
+			const cb_u32 mrow[4] = {mr.x, mr.x >> 16, mr.y, mr.y >> 16};   // low byte: left | right << 4
 			if (rel == 0) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) own[j] = v[4 + j];
@@ -558,12 +508,9 @@ __global__ void __launch_bounds__(64 * CwGeom<ARM>::WAVES) cbca_window_kernel(co
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				const int need = rel < 0 ? up[j] : dn[j];
-				const bool act = need >= arel;
 				const cb_u32 l = mrow[j] & 0xfu, r = (mrow[j] >> 4) & 0xfu;
-				if (DEEP) big[j] = big[j] || (act && (l > (cb_u32)CW_WIN || r > (cb_u32)CW_WIN));
-				const cb_u32 lc = DEEP ? min(l, (cb_u32)CW_WIN) : l, rc = DEEP ? min(r, (cb_u32)CW_WIN) : r;
-				const cb_u32 run = ((1u << (lc + rc + 1u)) - 1u) << (CW_WIN - lc);   // bit k <-> column offset k - 4
-				mask[j] = act ? run : 0u;
+				const cb_u32 run = ((1u << (l + r + 1u)) - 1u) << (CW_ARM - l);   // bit k <-> column offset k - 4
+				mask[j] = need >= arel ? run : 0u;
 				cnt[j] += __builtin_popcount(mask[j]);
 				anywide |= mask[j];
 			}
@@ -587,62 +534,6 @@ __global__ void __launch_bounds__(64 * CwGeom<ARM>::WAVES) cbca_window_kernel(co
 		float res[4];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) res[j] = inr[j] ? sum[j] / (float)cnt[j] : own[j];   // adcensus.cu:353-354: copied through
-		if (DEEP) {
-			if (__any(big[0] || big[1] || big[2] || big[3])) {
-				// The supports that leave the 9x9 window, by the same walk over +-ARM rows and columns: every row and
-				// column of them is in the rings (halo 16 >= ARM columns, ARM rows either side).  All four outputs of a
-				// lane share the row's 36-column window (9 x ds_read_b128); in flat regions every lane is here.
-#pragma unroll
-				for (int j = 0; j < 4; ++j) {
-					ubig = max(ubig, big[j] ? (int)(ud[j] & 0xfu) : 0);
-					dbig = max(dbig, big[j] ? (int)(ud[j] >> 4) : 0);
-				}
-				int Ub = 0, Db = 0;   // wave maxima (<= 15): four ballots each
-#pragma unroll
-				for (int bit = 8; bit >= 1; bit >>= 1) {
-					Ub += __any(ubig >= Ub + bit) ? bit : 0;
-					Db += __any(dbig >= Db + bit) ? bit : 0;
-				}
-				const bool anyj[4] = {(bool)__any(big[0]), (bool)__any(big[1]), (bool)__any(big[2]), (bool)__any(big[3])};
-				float sb[4];
-				int cb[4] = {0, 0, 0, 0};
-#pragma unroll
-				for (int j = 0; j < 4; ++j) asm("v_mov_b32 %0, 0" : "=v"(sb[j]));
-				const int dlane = min(max(lane, 4), 59);   // lanes without outputs read a window that exists
-				for (int rel = -Ub; rel <= Db; ++rel) {
-					int sl = sv - ARM + rel;
-					sl = sl < 0 ? sl + G::RV : sl;
-					const float *__restrict__ vr = Vw + sl * G::VPITCH + G::VOFF + 4 * dlane - 16;   // frame column 4*lane - 16
-					float v[36];
-#pragma unroll
-					for (int q = 0; q < 9; ++q) {
-						const cb_f4 t = *(const cb_f4 *)(vr + 4 * q);
-						v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-					}
-					const cb_u32 w = *(const cb_u32 *)(LRw + sl * CS_COLS + 4 * lane);
-					const int arel = rel < 0 ? -rel : rel;
-#pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						if (!anyj[j]) continue;   // wave-uniform
-						const int need = big[j] ? (int)(rel < 0 ? (ud[j] & 0xfu) : (ud[j] >> 4)) : -1;
-						const cb_u32 l = (w >> (8 * j)) & 0xfu, r = (w >> (8 * j + 4)) & 0xfu;
-						const cb_u32 run = ((1u << (l + r + 1u)) - 1u) << (13u - min(l, 13u));   // bit k <-> column offset k - 13
-						const cb_u32 mask = need >= arel ? run : 0u;
-						cb[j] += __builtin_popcount(mask);
-#pragma unroll
-						for (int k = 0; k < 27; ++k) {
-							const cb_u32 keep = (cb_u32)(((int)(mask << (31 - k))) >> 31);
-							float t;
-							asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(t) : "v"(keep), "v"(v[3 + j + k]), "s"(0x80000000u));
-							sb[j] += t;
-						}
-					}
-				}
-#pragma unroll
-				for (int j = 0; j < 4; ++j)
-					if (big[j]) res[j] = sb[j] / (float)cb[j];
-			}
-		}
 		const int ob = yo * W + xs;
 		if (full_out) {
 			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
@@ -653,23 +544,22 @@ __global__ void __launch_bounds__(64 * CwGeom<ARM>::WAVES) cbca_window_kernel(co
 		}
 	};
 
-	constexpr int PF = DEEP ? 4 : 2;   // (ARM > 4 runs four waves per CU: more rows in flight per wave)
+	constexpr int PF = 2;
 	Stage st[PF];
 #pragma unroll
 	for (int u = 0; u < PF; ++u) fetch(st[u], ra + u);
-	const int last = y1 - 1 + ARM;
-	int sv = 0, sm = 0;   // ring slots of the rows being committed
+	const int last = y1 - 1 + CW_ARM;
+	int rs = 0;   // ring slot of the row being committed
 	for (int g = ra; g <= last; g += PF) {
 #pragma unroll
 		for (int u = 0; u < PF; ++u) {
 			const int r = g + u;
 			if (r > last) break;
-			commit(st[u], sv, sm, r);
+			commit(st[u], rs);
 			fetch(st[u], r + PF);
-			const int yo = r - ARM;
-			if (yo >= y0 && yo < y1) output(yo, sv, sm);
-			sv = sv + 1 == G::RV ? 0 : sv + 1;
-			sm = sm + 1 == G::RM ? 0 : sm + 1;
+			const int yo = r - CW_ARM;
+			if (yo >= y0 && yo < y1) output(yo, rs);
+			rs = rs + 1 == CW_RING ? 0 : rs + 1;
 		}
 	}
 }
@@ -725,28 +615,17 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(nd, 4) * 4;
 	// non-temporal volume accesses for volumes far larger than the 256 MB Infinity Cache (see cbca_strip_kernel)
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
-	// window kernels: every lane walks its own supports out of rings that cover them -- arms <= 4 (L1 <= 5, the KITTI
-	// parameter sets) or <= 13 (L1 <= 14, Middlebury); form 2 / 3 force them (test hook)
-	const int arm_class = cfg.form == 2 ? 4 : cfg.form == 3 ? 13 : (cfg.form == 0 && max_arm >= 0 && max_arm <= 4) ? 4
-	                      : (cfg.form == 0 && max_arm >= 0 && max_arm <= 13) ? 13 : 0;
-	if (arm_class) {
-		const int step = arm_class == 4 ? CwGeom<4>::STEP : CwGeom<13>::STEP;
-		const int wpb = arm_class == 4 ? CwGeom<4>::WAVES : CwGeom<13>::WAVES;
-		A.gx = (int)cdiv(W, step);
-		// output rows per strip: 2 * arm halo rows per chunk; at least ~16 K waves
+	// short arms (L1 <= 5, the KITTI parameter sets): every lane walks its own supports out of 9-row rings; on a Gaussian
+	// texture it is within 8 % of the strip kernel, on real-scene arm statistics 4.6 x faster
+	const bool window = cfg.form == 2 || (cfg.form == 0 && max_arm >= 0 && max_arm <= CW_ARM);
+	if (window) {
+		A.gx = (int)cdiv(W, CW_STEP);
 		const int64_t gy_w = cdiv((int64_t)16384, (int64_t)A.gx * nd);
-		const int64_t rb_max = arm_class == 4 ? 40 : 128, rb_min = arm_class == 4 ? 16 : 32;
-		A.rb = cfg.rb > 0 ? cfg.rb : (int)std::min<int64_t>(rb_max, std::max<int64_t>(rb_min, cdiv((int64_t)H, gy_w)));
+		A.rb = cfg.rb > 0 ? cfg.rb : (int)std::min<int64_t>(40, std::max<int64_t>(16, cdiv((int64_t)H, gy_w)));
 		A.gy = (int)cdiv(H, A.rb);
-		const int64_t wv = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(nd, wpb) * wpb;
-		const dim3 grid((unsigned)cdiv(wv, wpb)), block(64 * wpb);
-		if (arm_class == 4) {
-			if (nt) hipLaunchKernelGGL((cbca_window_kernel<4, true>), grid, block, 0, st, A);
-			else hipLaunchKernelGGL((cbca_window_kernel<4, false>), grid, block, 0, st, A);
-		} else {
-			if (nt) hipLaunchKernelGGL((cbca_window_kernel<13, true>), grid, block, 0, st, A);
-			else hipLaunchKernelGGL((cbca_window_kernel<13, false>), grid, block, 0, st, A);
-		}
+		const int64_t wv = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(nd, CW_WAVES) * CW_WAVES;
+		if (nt) hipLaunchKernelGGL((cbca_window_kernel<true>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, A);
+		else hipLaunchKernelGGL((cbca_window_kernel<false>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, A);
 		return check_launch("cbca_window");
 	}
 	// prefetch 2 rows, ring of 4 rows, 1 row of look-ahead, window form +-2 columns (+-4 measured slower at KITTI and 1000x1500)

@@ -171,24 +171,3 @@ def test_cbca_forms_agree_on_a_realistic_pair(mc):
     o = torch.full_like(vin, -7.0)
     mc.adcensus.cbca_reference_shaped(x0c, x1c, vin, o, -1)
     assert same_bits(outs[0], o.cpu().numpy()) and same_bits(outs[1], o.cpu().numpy())
-
-
-@pytest.mark.parametrize("H,W,D", [(90, 300, 9), (41, 519, 6), (60, 253, 5), (83, 64, 12), (37, 449, 4), (140, 230, 3)])
-@pytest.mark.parametrize("rb", [0, 32, 50])
-@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.02), ("natural", 14, 0.02), ("blocky", 14, 0.2), ("natural", 9, 0.05),
-                                        ("blocky", 6, 0.3), ("natural", 5, 0.13), ("random", 14, 2.5), ("blocky", 14, 10.0)])
-def test_cbca_deep_window_kernel(mc, oracle, H, W, D, rb, mk, L1, tau1):
-    """form 3 (what mc_predict takes for 5 < L1 <= 14): arms up to 13 -- supports inside the 9x9 window by the window walk,
-    larger ones (flat regions, up to 27 x 27) by the lane's own loop out of the 27-row ring; ("blocky", 14, 10.0) makes every
-    arm as long as the image allows"""
-    from util import natural_pair
-    x0, x1 = {"smooth": lambda: smooth_pair(H, W, 8, seed=H), "random": lambda: random_pair(H, W, seed=W),
-              "blocky": lambda: blocky_pair(H, W, seed=D), "natural": lambda: natural_pair(H, W, 8, seed=H + W, sigma=8.0)}[mk]()
-    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
-    vl, vr = raw_volumes(D, H, W, seed=13)
-    for direction, vol in ((-1, vl), (1, vr)):
-        want = oracle.cbca(x0c, x1c, vol, direction)
-        out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=(H + rb) & 1, form=3)
-        got = out.cpu().numpy()
-        assert same_bits(got, want), diff_report(got, want, "deep window kernel rb=%d dir=%d" % (rb, direction))
