@@ -260,9 +260,12 @@ int mc_predict_timed(const mc_params *p, const float *x0, const float *x1,
 
 /* mc_cbca_ws with the launch configuration forced instead of derived from the problem: rows per strip `rb` (0 = auto),
  * cache policy `nt` (-1 = auto, 0 = default policy, 1 = non-temporal volume accesses), planes [d0, d0+nd) only
- * (nd = 0: all), kernel `form` (0 = the one mc_cbca_ws takes, 1 = strip kernel, 2 = window kernel -- the one mc_predict
- * takes for L1 <= 5; it requires every arm <= 4, i.e. arms from mc_cross with L1 <= 5).  Lets small-shape parity tests
- * reach the instantiations the benchmarked sizes and parameter sets select. */
+ * (nd = 0: all), kernel `form`: 0 = the one mc_cbca_ws takes, 1 = strip kernel, 2 = window kernel (what mc_predict
+ * takes for L1 <= 5; requires every arm <= 4, i.e. arms from mc_cross with L1 <= 5), 3 = strip kernel + list kernel
+ * (what mc_predict takes for L1 > 5: the supports that do not fit the strip kernel's window form are classified by size
+ * into a list behind the packed lengths -- scratch must hold mc_cbca_scratch_bytes + mc_cbca_list_bytes -- and walked a
+ * lane per entry).  Lets small-shape parity tests reach what the benchmarked sizes and parameter sets select. */
+size_t mc_cbca_list_bytes(int D, int H, int W);
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
                    int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
                    int rb, int nt, int d0, int nd, int form, void *stream);

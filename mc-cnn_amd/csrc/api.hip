@@ -38,7 +38,9 @@ int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, h
 int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
                      int direction, hipStream_t st);
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
-               hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
+               hipStream_t st, const CbcaCfg &cfg = CbcaCfg(), const void *listmem = nullptr);
+size_t cbca_list_bytes(int D, int H, int W);
+int cbca_list_build(const void *packed, void *listmem, int D, int H, int W, int direction, hipStream_t st);
 size_t conv3x3_workspace_bytes(int Cin, int Cout);
 int conv3x3(const float *in, const float *w, const float *bias, float *out, int N, int Cin, int Cout, int H, int W, int relu,
             void *workspace, hipStream_t st);
@@ -112,9 +114,16 @@ static int gaussian_cached(double sigma, GaussianK &out)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// cbca by lists: arms longer than the window kernel's (L1 > 5), short enough for the packed lengths, 32-bit voxel indices
+static bool cbca_listed_mode(int L1, int D, int H, int W)
+{
+	return L1 - 1 > 4 && L1 - 1 <= 254 && (int64_t)D * H * W < ((int64_t)1 << 31) && (int64_t)H * W < ((int64_t)1 << 29) - 4096;
+}
+
 struct Plan {
 	int Dp;                 // padded pixel stride of the (H,W,Dp) volumes
 	size_t maps, arms, pack, vol, img, gk;
+	size_t list;            // per direction: the outputs cbca_list_kernel owns (L1 > 5 only, else 0)
 	size_t total;
 };
 
@@ -131,7 +140,10 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	const int kr = (int)ceil(p->blur_sigma * 3);
 	const int ks = 2 * kr + 1;
 	pl.gk = align_up((size_t)ks * ks * sizeof(float), 256);
-	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk;
+	// long arms (L1 > 5): the supports that do not fit the strip kernel's window form are listed once per pair and direction
+	const bool uses_cbca = p->cbca_i1 + p->cbca_i2 > 0;
+	pl.list = (uses_cbca && cbca_listed_mode(p->L1, D, H, W)) ? cbca_list_bytes(D, H, W) : 0;
+	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk + 2 * pl.list;
 	return pl;
 }
 
@@ -203,6 +215,10 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	bufC[1] = (float *)w; w += pl.vol;
 	float *img[6];
 	for (int i = 0; i < 6; ++i) { img[i] = (float *)w; w += pl.img; }
+	void *lists[2] = {nullptr, nullptr};
+	if (pl.list) {
+		lists[0] = w + pl.gk; lists[1] = w + pl.gk + pl.list;   // behind the Gaussian kernel, which follows the images
+	}
 	float *gk = (float *)w;
 	const int Dp = pl.Dp;
 	int rc;
@@ -243,12 +259,20 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	// (mb_directions, main.lua:953-955) -- only when nothing of it is asked for
 	const int nvol = (p->left_only && !p->lr_check && !volR_out && !dispR0_out) ? 1 : 2;
 	// n CBCA iterations on the (D,H,W) volumes, ping-pong between the two buffers of each side (instead of vol:copy(tmp))
+	bool lists_built = false;
 	auto cbca_iterations = [&](int n) -> int {
 		const bool strips = cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096;  // packed lengths saturate at 255
+		if (n > 0 && pl.list && !lists_built) {  // long arms: classify the pair's supports once, for both aggregation blocks
+			for (int v = 0; v < nvol; ++v) {
+				const int rc2 = cbca_list_build(packed, lists[v], D, H, W, direction[v], st);
+				if (rc2) return rc2;
+			}
+			lists_built = true;
+		}
 		for (int i = 0; i < n; ++i) {
 			for (int v = 0; v < nvol; ++v) {
 				float *dst = other(v);
-				const int rc2 = strips ? cbca_strips(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st)
+				const int rc2 = strips ? cbca_strips(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st, CbcaCfg(), pl.list ? lists[v] : nullptr)
 				                       : cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st);
 				if (rc2) return rc2;
 				cur[v] = dst;
@@ -544,6 +568,8 @@ int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *v
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
 }
 
+size_t mc_cbca_list_bytes(int D, int H, int W) { return cbca_list_bytes(D, H, W); }
+
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
                    void *scratch, size_t scratch_bytes, int rb, int nt, int d0, int nd, int form, void *stream)
 {
@@ -555,14 +581,25 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
 	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws_cfg: image too large for 32-bit plane offsets");
-	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 2, "mc_cbca_ws_cfg: bad rb / nt / form");
+	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 3, "mc_cbca_ws_cfg: bad rb / nt / form");
 	MC_REQUIRE(d0 >= 0 && nd >= 0 && d0 + nd <= D, "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
 	CbcaCfg cfg;
-	cfg.rb = rb; cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd; cfg.form = form;
-	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg);
+	cfg.rb = rb; cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd; cfg.form = form == 3 ? 1 : form;
+	const void *listmem = nullptr;
+	if (form == 3) {  // strip kernel + list kernel (what mc_predict runs for L1 > 5): the list lives behind the packed lengths
+		MC_REQUIRE(d0 == 0 && nd == 0, "mc_cbca_ws_cfg: form 3 processes whole volumes");
+		MC_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 31), "mc_cbca_ws_cfg: form 3 needs D*H*W < 2^31");
+		MC_REQUIRE(scratch_bytes >= cbca_scratch_bytes(H, W) + cbca_list_bytes(D, H, W), "mc_cbca_ws_cfg: form 3 needs %zu bytes of scratch",
+		           cbca_scratch_bytes(H, W) + cbca_list_bytes(D, H, W));
+		void *lm = (char *)scratch + cbca_scratch_bytes(H, W);
+		rc = cbca_list_build(scratch, lm, D, H, W, direction, st);
+		if (rc) return rc;
+		listmem = lm;
+	}
+	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg, listmem);
 	if (rc) return rc;
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
 }

@@ -129,10 +129,10 @@ __global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict_
 // the row of results in LDS before it is stored.
 // CS_RING rows per ring, CS_LA rows committed below (and staged above) the current output row, CS_WR column radius of
 // the window form
-template <int PF, int CS_RING, int CS_LA, int CS_WR, bool NT>
+template <int PF, int CS_RING, int CS_LA, int CS_WR, bool NT, bool LISTED>
 __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 {
-	constexpr int CS_UP = CS_LA;
+	constexpr int CS_UP = 2;   // rows staged above the first output row: the window form reaches two rows up
 	// cache policy of the volume rows: nt (bit 1) for volumes far larger than the 256 MB MALL -- streamed once, only the
 	// region's packed lengths should stay cached; smaller volumes (KITTI: 414 MB) are partly served from the MALL on the
 	// next iteration and measured faster without the hint
@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 						for (int t = 0; t < 2 * CS_WR + 1; ++t) tv[k][t] = V[ro_ + t - CS_WR];
 					}
 					bool ok = u <= 2 && dn <= CS_LA && yo - u >= lo_row && yo + dn <= hi_row;
+					bool fits = u <= 2 && dn <= CS_LA;   // the support's shape alone (cbca_fits_window): inside rows -2 .. +LA, columns +-WR
 					float sum = 0;
 					int cnt = 0;
 #pragma unroll
@@ -327,6 +328,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 						const bool act = rel >= -u && rel <= dn;
 						const int l = (int)(mm[k] & 0xff), rg = (int)((mm[k] >> 8) & 0xff);
 						ok = ok && (!act || (l <= CS_WR && rg <= CS_WR && c - l >= 0 && c + rg < CS_COLS));
+						fits = fits && (!act || (l <= CS_WR && rg <= CS_WR));
 						const int la = act ? l : -1, rga = act ? rg : -1;   // inactive row: no tap passes
 #pragma unroll
 						for (int t = 0; t < 2 * CS_WR + 1; ++t) {
@@ -336,7 +338,10 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 						}
 						cnt += act ? l + rg + 1 : 0;
 					}
-					R[c] = ok ? sum / (float)cnt : general(yo, c, u, dn, lo_row, hi_row);
+					// LISTED: a support that does not fit the window by its shape is in the pair's list and is left to
+					// cbca_list_kernel, which runs after this launch (the value stored here is provisional)
+					if (ok) R[c] = sum / (float)cnt;
+					else if (!LISTED || fits) R[c] = general(yo, c, u, dn, lo_row, hi_row);
 				}
 			}
 			const cb_f2 r0 = *(const cb_f2 *)(R + c0 + 2), r1 = *(const cb_f2 *)(R + c1 + (lane < 63 ? 0 : 2));
@@ -564,6 +569,230 @@ __global__ void __launch_bounds__(64 * CW_WAVES) cbca_window_kernel(const CbcaAr
 	}
 }
 
+// =====================================================================================================
+// cbca for long arms (L1 > 5): supports sorted by size, once per pair
+// =====================================================================================================
+// On real scenes under the Middlebury thresholds (L1 = 14, tau1 = 0.02) half of the supports are the minimal 3x3, 84 %
+// hold at most 25 taps and 4-6 % are flat regions of up to 27 x 27 = 729 taps that carry two thirds of all additions
+// (tests/util.natural_pair).  Every output is ONE serial chain of additions, so a wave runs at the pace of its largest
+// support: the strip kernel's per-row passes (56 ms per launch at 1000x1500x256) and one thread per voxel (21 ms) both
+// spend most of their lanes waiting.  The supports do not change between the 2 + 16 iterations of a pair, so they are
+// classified ONCE per pair and direction: every output whose support does not fit the strip kernel's window form by its
+// shape goes, by size class, into a list of voxel indices (count pass, prefix, fill pass).  Per iteration the strip kernel
+// (LISTED) then skips those outputs and cbca_list_kernel walks the list, a lane per entry: the lanes of a wave hold
+// supports of one size class, and a persistent grid strides over the list so that all CUs work on the same class at a time.
+constexpr int CL_BUCKETS = 8;
+constexpr int CL_BLOCKS = 2048;   // persistent grid of the classification passes (8 blocks per CU)
+struct CbcaListHdr {
+	uint32_t total;
+	uint32_t pad[31];
+	uint32_t block[CL_BLOCKS][CL_BUCKETS];   // count pass: entries of block k in class b; after the scan: its first entry
+};
+
+__device__ __forceinline__ int cl_bucket(int size)
+{
+	return size <= 12 ? 0 : size <= 20 ? 1 : size <= 32 ? 2 : size <= 56 ? 3 : size <= 100 ? 4 : size <= 200 ? 5 : size <= 400 ? 6 : 7;
+}
+
+// shape test shared with the strip kernel (its `fits`): rows -2 .. +1, columns +-2 -- and the support's tap count
+__device__ __forceinline__ bool cbca_listed(const uint32_t *__restrict__ p0, const uint32_t *__restrict__ p1, int y, int x, int sh, int W,
+                                            int &size)
+{
+	const int g0 = y * W + x;
+	const uint32_t own = bytemin4(p0[g0], p1[g0 + sh]);
+	const int u = (int)((own >> 16) & 0xff), dn = (int)(own >> 24);
+	bool fits = u <= 2 && dn <= 1;
+	int n = 0;
+	for (int q = y - u; q <= y + dn; ++q) {
+		const int g = q * W + x;
+		const uint32_t mm = q == y ? own : bytemin4(p0[g], p1[g + sh]);
+		const int l = (int)(mm & 0xff), r = (int)((mm >> 8) & 0xff);
+		fits = fits && l <= 2 && r <= 2;
+		n += l + r + 1;
+	}
+	size = n;
+	return !fits;
+}
+
+// A block owns a contiguous range of (plane, 4 rows, 64 columns) tiles and keeps its eight class counters in LDS:
+// FILL = false classifies its outputs (class byte per voxel, 0xff = not listed) and counts them per class, FILL = true
+// (after the scan has turned the counts into first positions) walks the same tiles again, reads the class bytes and
+// writes the voxel indices.  No global atomics.
+template <bool FILL>
+__global__ void __launch_bounds__(256) cbca_list_build_kernel(const uint32_t *__restrict__ p0, const uint32_t *__restrict__ p1,
+                                                              CbcaListHdr *__restrict__ hdr, uint32_t *__restrict__ list,
+                                                              uint8_t *__restrict__ cls, int D, int H, int W, int direction)
+{
+	__shared__ uint32_t cur[CL_BUCKETS];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if (threadIdx.x < CL_BUCKETS) cur[threadIdx.x] = FILL ? hdr->block[blockIdx.x][threadIdx.x] : 0u;
+	__syncthreads();
+	const int tx = (W + 63) >> 6, ty = (H + 3) >> 2;
+	const int64_t tiles = (int64_t)tx * ty * D;
+	const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
+	const int64_t t0 = per * blockIdx.x, t1 = min(tiles, t0 + per);
+	for (int64_t t = t0; t < t1; ++t) {
+		const int bx = (int)(t % tx), by = (int)((t / tx) % ty), d = (int)(t / ((int64_t)tx * ty));
+		const int x = bx * 64 + lane, y = by * 4 + wv;
+		const int sh = d * direction;
+		const bool inside = x < W && y < H;
+		const uint32_t id = (uint32_t)((d * H + y) * W + x);
+		int bucket = -1;
+		if (FILL) {
+			if (inside) bucket = (int)(int8_t)cls[id];   // 0xff -> -1
+		} else {
+			if (inside && x + sh >= 0 && x + sh < W) {
+				int size;
+				if (cbca_listed(p0, p1, y, x, sh, W, size)) bucket = cl_bucket(size);
+			}
+			if (inside) cls[id] = (uint8_t)bucket;
+		}
+		if (!__any(bucket >= 0)) continue;   // wave-uniform: nothing listed in this row of the tile
+#pragma unroll
+		for (int b = 0; b < CL_BUCKETS; ++b) {
+			const unsigned long long m = __ballot(bucket == b);
+			if (m == 0) continue;   // wave-uniform
+			const int leader = __builtin_ctzll(m);
+			uint32_t start = 0;
+			if (lane == leader) start = atomicAdd(&cur[b], (uint32_t)__builtin_popcountll(m));
+			if (FILL) {
+				start = (uint32_t)__builtin_amdgcn_readlane((int)start, leader);
+				const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+				if (bucket == b) list[start + rank] = id;
+			}
+		}
+	}
+	if (!FILL) {
+		__syncthreads();
+		if (threadIdx.x < CL_BUCKETS) hdr->block[blockIdx.x][threadIdx.x] = cur[threadIdx.x];
+	}
+}
+
+// counts -> first positions: block after block (a block's tiles are one compact region of the volume, so that region's
+// entries are consecutive in the list and meet in one L2), inside a block class after class (the 64 consecutive entries
+// of a wave are of one size class except at the few class boundaries)
+__global__ void __launch_bounds__(256) cbca_list_scan_kernel(CbcaListHdr *__restrict__ hdr)
+{
+	constexpr int PER = CL_BLOCKS / 256;
+	__shared__ uint32_t part[256];
+	uint32_t mine = 0;
+	for (int k = threadIdx.x * PER; k < (threadIdx.x + 1) * PER; ++k)
+		for (int b = 0; b < CL_BUCKETS; ++b) mine += hdr->block[k][b];
+	part[threadIdx.x] = mine;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t run = 0;
+		for (int t = 0; t < 256; ++t) {
+			const uint32_t n = part[t];
+			part[t] = run;
+			run += n;
+		}
+		hdr->total = run;
+	}
+	__syncthreads();
+	uint32_t run = part[threadIdx.x];
+	for (int k = threadIdx.x * PER; k < (threadIdx.x + 1) * PER; ++k) {
+		for (int b = 0; b < CL_BUCKETS; ++b) {
+			const uint32_t n = hdr->block[k][b];
+			hdr->block[k][b] = run;
+			run += n;
+		}
+	}
+}
+
+// one lane per list entry; the reference's loop (adcensus.cu:356-373) with the lengths from the packed maps.  The lanes
+// of a wave hold supports of one size class, so they leave the loops together; what is left to hide is the latency of
+// a row's lengths and of its values: the next row's lengths are fetched before the current row is summed, and a row's
+// values are fetched sixteen at a time.
+typedef float cl_f4u __attribute__((ext_vector_type(4), aligned(4)));   // four floats at any dword address
+
+template <bool NT>
+__global__ void __launch_bounds__(256) cbca_list_kernel(const uint32_t *__restrict__ list, const CbcaListHdr *__restrict__ hdr, const CbcaArgs A)
+{
+	const uint32_t total = hdr->total;
+	const int H = A.H, W = A.W, HWi = H * W;
+	// the grid takes the list in windows of gridDim.x chunks of 256 entries; inside a window the blocks of one XCD
+	// (blockIdx % 8) take CONSECUTIVE chunks, so that neighbouring supports meet in one L2 (round-robin chunks made every
+	// XCD miss on the same lines: 52 GB of fills per launch for a 1.5 GB volume)
+	const uint32_t stride = gridDim.x * 256u;
+	const uint32_t slot = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+	for (uint32_t i = slot * 256u + threadIdx.x; i < total; i += stride) {
+		const uint32_t id = list[i];
+		const int d = (int)(id / (uint32_t)HWi);
+		const int rem = (int)(id - (uint32_t)d * (uint32_t)HWi);
+		const int y = rem / W, x = rem - y * W;
+		const int sh = d * A.direction;
+		const float *__restrict__ plane = A.vin + (size_t)d * HWi;
+		const uint32_t *__restrict__ q0 = A.p0 + x, *__restrict__ q1 = A.p1 + x + sh;
+		const uint32_t own = bytemin4(q0[y * W], q1[y * W]);
+		const int u = (int)((own >> 16) & 0xff), dn = (int)(own >> 24);
+		float sum = 0;
+		int cnt = 0;
+		uint32_t nxt = bytemin4(q0[(y - u) * W], q1[(y - u) * W]);
+		for (int q = y - u; q <= y + dn; ++q) {
+			const uint32_t mm = nxt;
+			const int qn = min(q + 1, y + dn);
+			nxt = bytemin4(q0[qn * W], q1[qn * W]);   // the next row's lengths travel while this row is summed
+			const int l = (int)(mm & 0xff), r = (int)((mm >> 8) & 0xff);
+			const int n = l + r + 1;
+			const float *__restrict__ row = plane + q * W + x - l;
+			// four values per load (the run starts anywhere: dword-aligned 16-byte loads), up to 16 in flight; a gather of
+			// single dwords costs the texture path one cache line per lane and instruction, and was 4x the time
+			int k = 0;
+			for (; k + 16 <= n; k += 16) {
+				cl_f4u v[4];
+#pragma unroll
+				for (int t = 0; t < 4; ++t) v[t] = *(const cl_f4u *)(row + k + 4 * t);
+#pragma unroll
+				for (int t = 0; t < 4; ++t) { sum += v[t].x; sum += v[t].y; sum += v[t].z; sum += v[t].w; }
+			}
+			if (k + 8 <= n) {
+				const cl_f4u v0 = *(const cl_f4u *)(row + k), v1 = *(const cl_f4u *)(row + k + 4);
+				sum += v0.x; sum += v0.y; sum += v0.z; sum += v0.w;
+				sum += v1.x; sum += v1.y; sum += v1.z; sum += v1.w;
+				k += 8;
+			}
+			if (k + 4 <= n) {
+				const cl_f4u v0 = *(const cl_f4u *)(row + k);
+				sum += v0.x; sum += v0.y; sum += v0.z; sum += v0.w;
+				k += 4;
+			}
+			if (k < n) {   // 1 .. 3 left: single loads (a 16-byte load could reach past the end of the volume)
+				const float a0 = row[k], a1 = row[min(k + 1, n - 1)], a2 = row[min(k + 2, n - 1)];
+				sum += a0;
+				if (k + 1 < n) sum += a1;
+				if (k + 2 < n) sum += a2;
+			}
+			cnt += n;
+		}
+		const float res = sum / (float)cnt;
+		if (NT) __builtin_nontemporal_store(res, A.vout + (size_t)d * HWi + rem);
+		else A.vout[(size_t)d * HWi + rem] = res;
+	}
+}
+
+// header + one 32-bit voxel index per output (worst case: every output is listed) + one class byte per voxel
+static size_t cl_list_words(int D, int H, int W) { return ((size_t)D * H * W + 63) & ~(size_t)63; }
+size_t cbca_list_bytes(int D, int H, int W)
+{
+	return (sizeof(CbcaListHdr) + cl_list_words(D, H, W) * sizeof(uint32_t) + (size_t)D * H * W + 255) & ~(size_t)255;
+}
+
+// classification of a (pair, direction): which outputs the list kernel owns, sorted by support size.  Arms <= 254 and
+// D*H*W < 2^31 required (callers check).
+int cbca_list_build(const void *packed, void *listmem, int D, int H, int W, int direction, hipStream_t st)
+{
+	const CbcaScratch cs = cbca_scratch(packed, H, W);
+	CbcaListHdr *hdr = (CbcaListHdr *)listmem;
+	uint32_t *list = (uint32_t *)((char *)listmem + sizeof(CbcaListHdr));
+	uint8_t *cls = (uint8_t *)(list + cl_list_words(D, H, W));
+	const dim3 grid(CL_BLOCKS), block(256);
+	hipLaunchKernelGGL((cbca_list_build_kernel<false>), grid, block, 0, st, cs.p0, cs.p1, hdr, list, cls, D, H, W, direction);
+	hipLaunchKernelGGL(cbca_list_scan_kernel, dim3(1), dim3(256), 0, st, hdr);
+	hipLaunchKernelGGL((cbca_list_build_kernel<true>), grid, block, 0, st, cs.p0, cs.p1, hdr, list, cls, D, H, W, direction);
+	return check_launch("cbca_list_build");
+}
+
 size_t cbca_scratch_bytes(int H, int W) { return (((size_t)2 * H * W + 3 * CS_PAD + 1) * sizeof(uint32_t) + 255) & ~(size_t)255; }
 
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st)
@@ -595,7 +824,7 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
 // Arm lengths saturate at 255 in the packed form: callers route max_arm > 254 to the direct kernel.
 // cfg (mc_common.h): rows per strip, cache policy and plane range; zero / negative fields = derived from the size.
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm, hipStream_t st,
-                const CbcaCfg &cfg)
+                const CbcaCfg &cfg, const void *listmem)
 {
 	const int d0 = cfg.nd > 0 ? cfg.d0 : 0, nd = cfg.nd > 0 ? cfg.nd : D;
 	CbcaArgs A;
@@ -629,8 +858,20 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 		return check_launch("cbca_window");
 	}
 	// prefetch 2 rows, ring of 4 rows, 1 row of look-ahead, window form +-2 columns (+-4 measured slower at KITTI and 1000x1500)
-	if (nt) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
-	else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+	if (listmem) {
+		// the pair's list (cbca_list_build) owns the supports that do not fit the window form; the list kernel follows on
+		// the same stream and overwrites the provisional values the strip kernel stored for them
+		if (nt) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true, true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+		else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, false, true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+		const CbcaListHdr *hdr = (const CbcaListHdr *)listmem;
+		const uint32_t *list = (const uint32_t *)((const char *)listmem + sizeof(CbcaListHdr));
+		const dim3 lgrid(256 * 8);   // persistent: 8 blocks per CU stride over the list
+		if (nt) hipLaunchKernelGGL((cbca_list_kernel<true>), lgrid, dim3(256), 0, st, list, hdr, A);
+		else hipLaunchKernelGGL((cbca_list_kernel<false>), lgrid, dim3(256), 0, st, list, hdr, A);
+		return check_launch("cbca_strip + cbca_list");
+	}
+	if (nt) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+	else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, false, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
 	return check_launch("cbca_strip");
 }
 

@@ -31,6 +31,7 @@ struct CbcaCfg {
 	int nt = -1;       // volume cache policy: -1 auto, 0 default, 1 non-temporal
 	int d0 = 0, nd = 0;// planes [d0, d0 + nd) only (nd = 0: all)
 	int form = 0;      // kernel: 0 auto (by the largest possible arm), 1 strip kernel, 2 window kernel (arms <= 4 only)
+	                   // (the hook's form 3 = strip kernel + the pair's list, is not a cfg value)
 };
 
 // ---- wave64 cross-lane primitives (DPP, no LDS round trip) -------------------

@@ -171,3 +171,44 @@ def test_cbca_forms_agree_on_a_realistic_pair(mc):
     o = torch.full_like(vin, -7.0)
     mc.adcensus.cbca_reference_shaped(x0c, x1c, vin, o, -1)
     assert same_bits(outs[0], o.cpu().numpy()) and same_bits(outs[1], o.cpu().numpy())
+
+
+# ---- strip kernel + the pair's list of large supports (cbca form 3: what mc_predict takes for L1 > 5) -----------------
+@pytest.mark.parametrize("H,W,D", [(90, 300, 9), (41, 519, 6), (60, 253, 5), (83, 64, 12), (37, 449, 4), (140, 230, 3)])
+@pytest.mark.parametrize("rb", [0, 25])
+@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.02), ("natural", 14, 0.02), ("blocky", 14, 0.2), ("natural", 9, 0.05),
+                                        ("blocky", 6, 0.3), ("natural", 5, 0.13), ("random", 14, 2.5), ("blocky", 34, 10.0)])
+def test_cbca_listed(mc, oracle, H, W, D, rb, mk, L1, tau1):
+    """supports that do not fit the strip kernel's window form come from the list kernel: every kind of arm statistics, up
+    to arms as long as the image allows (("blocky", 34, 10.0)), both directions, both cache policies"""
+    from util import natural_pair
+    x0, x1 = {"smooth": lambda: smooth_pair(H, W, 8, seed=H), "random": lambda: random_pair(H, W, seed=W),
+              "blocky": lambda: blocky_pair(H, W, seed=D), "natural": lambda: natural_pair(H, W, 8, seed=H + W, sigma=8.0)}[mk]()
+    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
+    vl, vr = raw_volumes(D, H, W, seed=13)
+    for direction, vol in ((-1, vl), (1, vr)):
+        want = oracle.cbca(x0c, x1c, vol, direction)
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=(H + rb) & 1, form=3)
+        got = out.cpu().numpy()
+        assert same_bits(got, want), diff_report(got, want, "listed rb=%d dir=%d" % (rb, direction))
+
+
+def test_cbca_listed_special_values(mc, oracle):
+    H, W, D = 40, 260, 6
+    x0, x1 = blocky_pair(H, W, seed=8)
+    x0c, x1c = oracle.cross(x0, 14, 0.2), oracle.cross(x1, 14, 0.2)
+    vl, _ = raw_volumes(D, H, W, seed=3)
+    rng = np.random.default_rng(1)
+    vl[0, :, 20:] = 0.0
+    vl[1, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-42)
+    vl[3, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(3e38)
+    for k in range(40):
+        vl[4, rng.integers(0, H), rng.integers(20, W)] = np.inf if k & 1 else np.nan
+    vl[5, 25:, 20:] = -0.0
+    with np.errstate(all="ignore"):
+        want = oracle.cbca(x0c, x1c, vl, -1)
+    out = torch.full((1, D, H, W), -7.0, device="cuda")
+    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, form=3)
+    got = out.cpu().numpy()
+    assert same_bits(got, want), diff_report(got, want, "listed, special values")
