@@ -700,28 +700,48 @@ __global__ void __launch_bounds__(256) cbca_list_scan_kernel(CbcaListHdr *__rest
 	}
 }
 
+// unsigned 32-bit division by a launch-time constant: q = (t + ((n - t) >> 1)) >> (s - 1), t = umulhi(n, M)
+struct ClDiv { uint32_t M, s1; };
+static ClDiv cl_div_make(uint32_t dv)   // dv >= 2
+{
+	uint32_t s = 0;
+	while (((uint64_t)1 << s) < dv) ++s;
+	ClDiv r;
+	r.M = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << s) - dv)) / dv + 1);
+	r.s1 = s - 1;
+	return r;
+}
+__device__ __forceinline__ uint32_t cl_div(uint32_t n, ClDiv dv)
+{
+	const uint32_t t = __umulhi(n, dv.M);
+	return (t + ((n - t) >> 1)) >> dv.s1;
+}
+
 // one lane per list entry; the reference's loop (adcensus.cu:356-373) with the lengths from the packed maps.  The lanes
-// of a wave hold supports of one size class, so they leave the loops together; what is left to hide is the latency of
-// a row's lengths and of its values: the next row's lengths are fetched before the current row is summed, and a row's
-// values are fetched sixteen at a time.
+// of a wave hold supports of one size class, so they leave the loops together.  Most entries are small supports whose
+// cost is per-entry and per-row overhead, not additions: the voxel index is split with multiplications, the next row's
+// lengths are fetched before the current row is summed, a run of up to 8 / 16 values is fetched whole with two / four
+// 16-byte loads (dword-aligned: the run starts anywhere; values behind the run's end are fetched but never added) and
+// longer runs 16 values at a time.
 typedef float cl_f4u __attribute__((ext_vector_type(4), aligned(4)));   // four floats at any dword address
 
 template <bool NT>
-__global__ void __launch_bounds__(256) cbca_list_kernel(const uint32_t *__restrict__ list, const CbcaListHdr *__restrict__ hdr, const CbcaArgs A)
+__global__ void __launch_bounds__(256) cbca_list_kernel(const uint32_t *__restrict__ list, const CbcaListHdr *__restrict__ hdr, const CbcaArgs A,
+                                                        const ClDiv divHW, const ClDiv divW)
 {
 	const uint32_t total = hdr->total;
 	const int H = A.H, W = A.W, HWi = H * W;
+	const uint32_t nvox = (uint32_t)A.D * (uint32_t)HWi;
 	// the grid takes the list in windows of gridDim.x chunks of 256 entries; inside a window the blocks of one XCD
-	// (blockIdx % 8) take CONSECUTIVE chunks, so that neighbouring supports meet in one L2 (round-robin chunks made every
-	// XCD miss on the same lines: 52 GB of fills per launch for a 1.5 GB volume)
+	// (blockIdx % 8) take CONSECUTIVE chunks, so that neighbouring supports meet in one L2
 	const uint32_t stride = gridDim.x * 256u;
 	const uint32_t slot = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 	for (uint32_t i = slot * 256u + threadIdx.x; i < total; i += stride) {
 		const uint32_t id = list[i];
-		const int d = (int)(id / (uint32_t)HWi);
-		const int rem = (int)(id - (uint32_t)d * (uint32_t)HWi);
-		const int y = rem / W, x = rem - y * W;
-		const int sh = d * A.direction;
+		const uint32_t d = cl_div(id, divHW);
+		const uint32_t rem = id - d * (uint32_t)HWi;
+		const int y = (int)cl_div(rem, divW), x = (int)rem - y * W;
+		const int sh = (int)d * A.direction;
 		const float *__restrict__ plane = A.vin + (size_t)d * HWi;
 		const uint32_t *__restrict__ q0 = A.p0 + x, *__restrict__ q1 = A.p1 + x + sh;
 		const uint32_t own = bytemin4(q0[y * W], q1[y * W]);
@@ -735,39 +755,53 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const uint32_t *__restri
 			nxt = bytemin4(q0[qn * W], q1[qn * W]);   // the next row's lengths travel while this row is summed
 			const int l = (int)(mm & 0xff), r = (int)((mm >> 8) & 0xff);
 			const int n = l + r + 1;
-			const float *__restrict__ row = plane + q * W + x - l;
-			// four values per load (the run starts anywhere: dword-aligned 16-byte loads), up to 16 in flight; a gather of
-			// single dwords costs the texture path one cache line per lane and instruction, and was 4x the time
-			int k = 0;
-			for (; k + 16 <= n; k += 16) {
-				cl_f4u v[4];
+			const int ro = q * W + x - l;
+			const float *__restrict__ row = plane + ro;
+			// 16 floats from the run's start stay inside the volume (the last rows of the last plane take the exact path)
+			const bool whole = n <= 16 && d * (uint32_t)HWi + (uint32_t)ro + 16u <= nvox;
+			if (whole) {
+				const cl_f4u v0 = *(const cl_f4u *)row, v1 = *(const cl_f4u *)(row + 4);
+				const float a[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-				for (int t = 0; t < 4; ++t) v[t] = *(const cl_f4u *)(row + k + 4 * t);
+				for (int t = 0; t < 8; ++t) sum += t < n ? a[t] : -0.0f;   // x + (-0.0f) == x: the values behind the run are no operands
+				if (n > 8) {
+					const cl_f4u v2 = *(const cl_f4u *)(row + 8), v3 = *(const cl_f4u *)(row + 12);
+					const float b[8] = {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 #pragma unroll
-				for (int t = 0; t < 4; ++t) { sum += v[t].x; sum += v[t].y; sum += v[t].z; sum += v[t].w; }
-			}
-			if (k + 8 <= n) {
-				const cl_f4u v0 = *(const cl_f4u *)(row + k), v1 = *(const cl_f4u *)(row + k + 4);
-				sum += v0.x; sum += v0.y; sum += v0.z; sum += v0.w;
-				sum += v1.x; sum += v1.y; sum += v1.z; sum += v1.w;
-				k += 8;
-			}
-			if (k + 4 <= n) {
-				const cl_f4u v0 = *(const cl_f4u *)(row + k);
-				sum += v0.x; sum += v0.y; sum += v0.z; sum += v0.w;
-				k += 4;
-			}
-			if (k < n) {   // 1 .. 3 left: single loads (a 16-byte load could reach past the end of the volume)
-				const float a0 = row[k], a1 = row[min(k + 1, n - 1)], a2 = row[min(k + 2, n - 1)];
-				sum += a0;
-				if (k + 1 < n) sum += a1;
-				if (k + 2 < n) sum += a2;
+					for (int t = 0; t < 8; ++t) sum += 8 + t < n ? b[t] : -0.0f;
+				}
+			} else {
+				int k = 0;
+				for (; k + 16 <= n; k += 16) {
+					cl_f4u v[4];
+#pragma unroll
+					for (int t = 0; t < 4; ++t) v[t] = *(const cl_f4u *)(row + k + 4 * t);
+#pragma unroll
+					for (int t = 0; t < 4; ++t) { sum += v[t].x; sum += v[t].y; sum += v[t].z; sum += v[t].w; }
+				}
+				if (k + 8 <= n) {
+					const cl_f4u v0 = *(const cl_f4u *)(row + k), v1 = *(const cl_f4u *)(row + k + 4);
+					sum += v0.x; sum += v0.y; sum += v0.z; sum += v0.w;
+					sum += v1.x; sum += v1.y; sum += v1.z; sum += v1.w;
+					k += 8;
+				}
+				if (k + 4 <= n) {
+					const cl_f4u v0 = *(const cl_f4u *)(row + k);
+					sum += v0.x; sum += v0.y; sum += v0.z; sum += v0.w;
+					k += 4;
+				}
+				if (k < n) {   // 1 .. 3 left: single loads (a 16-byte load could reach past the end of the volume)
+					const float a0 = row[k], a1 = row[min(k + 1, n - 1)], a2 = row[min(k + 2, n - 1)];
+					sum += a0;
+					if (k + 1 < n) sum += a1;
+					if (k + 2 < n) sum += a2;
+				}
 			}
 			cnt += n;
 		}
 		const float res = sum / (float)cnt;
-		if (NT) __builtin_nontemporal_store(res, A.vout + (size_t)d * HWi + rem);
-		else A.vout[(size_t)d * HWi + rem] = res;
+		if (NT) __builtin_nontemporal_store(res, A.vout + id);
+		else A.vout[id] = res;
 	}
 }
 
@@ -866,8 +900,9 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 		const CbcaListHdr *hdr = (const CbcaListHdr *)listmem;
 		const uint32_t *list = (const uint32_t *)((const char *)listmem + sizeof(CbcaListHdr));
 		const dim3 lgrid(256 * 8);   // persistent: 8 blocks per CU stride over the list
-		if (nt) hipLaunchKernelGGL((cbca_list_kernel<true>), lgrid, dim3(256), 0, st, list, hdr, A);
-		else hipLaunchKernelGGL((cbca_list_kernel<false>), lgrid, dim3(256), 0, st, list, hdr, A);
+		const ClDiv dHW = cl_div_make((uint32_t)H * (uint32_t)W), dW = cl_div_make((uint32_t)W);
+		if (nt) hipLaunchKernelGGL((cbca_list_kernel<true>), lgrid, dim3(256), 0, st, list, hdr, A, dHW, dW);
+		else hipLaunchKernelGGL((cbca_list_kernel<false>), lgrid, dim3(256), 0, st, list, hdr, A, dHW, dW);
 		return check_launch("cbca_strip + cbca_list");
 	}
 	if (nt) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
