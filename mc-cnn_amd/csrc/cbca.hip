@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict_
 	auto sat = [](int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
 	packed[id] = sat(l) | (sat(r) << 8) | (sat(u) << 16) | (sat(d) << 24);
 	if (overflow && (l > 254 || r > 254 || u > 254 || d > 254)) atomicOr(overflow, 1u);
+	if (overflow && (l > 4 || r > 4 || u > 4 || d > 4)) atomicOr(overflow + 1, 1u);   // an arm the window kernel does not cover
 }
 
 // =====================================================================================================
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 	__shared__ cb_u32 Mring[4][CS_RING * CS_COLS];
 	__shared__ float Rrow[4][CS_COLS];          // results of the current row (patched by the compacted pass)
 	__shared__ cb_u32 Clist[4][CS_COLS];        // outputs that need the general loop: frame column | up << 16 | down << 24
-	if (A.overflow && *A.overflow) return;
+	if (A.overflow && (A.overflow[0] || (A.by_arm && !A.overflow[1]))) return;   // (by_arm: the pair has short arms only, the window kernel runs)
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane descriptors stay in SGPRs
 	float *__restrict__ V = Vring[wv];
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(64 * CW_WAVES) cbca_window_kernel(const CbcaAr
 	constexpr int VOL_AUX = NT ? 2 : 0;
 	__shared__ __attribute__((aligned(16))) float Vring[CW_WAVES][CW_RING][CW_VPITCH];
 	__shared__ __attribute__((aligned(16))) unsigned short Mring[CW_WAVES][CW_RING][CS_COLS];
-	if (A.overflow && *A.overflow) return;
+	if (A.overflow && (A.overflow[0] || (A.by_arm && A.overflow[1]))) return;   // (by_arm: the pair has an arm > 4, the strip kernel runs)
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int H = A.H, W = A.W, direction = A.direction;
@@ -827,14 +828,14 @@ int cbca_list_build(const void *packed, void *listmem, int D, int H, int W, int 
 	return check_launch("cbca_list_build");
 }
 
-size_t cbca_scratch_bytes(int H, int W) { return (((size_t)2 * H * W + 3 * CS_PAD + 1) * sizeof(uint32_t) + 255) & ~(size_t)255; }
+size_t cbca_scratch_bytes(int H, int W) { return (((size_t)2 * H * W + 3 * CS_PAD + 2) * sizeof(uint32_t) + 255) & ~(size_t)255; }
 
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st)
 {
 	const CbcaScratch cs = cbca_scratch(scratch, H, W);
 	uint32_t *p0 = cs.p0, *p1 = cs.p1, *flag = cs.flag;
 	const int64_t HW = (int64_t)H * W;
-	const hipError_t e = hipMemsetAsync(flag, 0, sizeof(uint32_t), st);
+	const hipError_t e = hipMemsetAsync(flag, 0, 2 * sizeof(uint32_t), st);
 	if (e != hipSuccess) {
 		set_error("cbca_pack: %s", hipGetErrorString(e));
 		return (int)e;
@@ -879,17 +880,21 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	// non-temporal volume accesses for volumes far larger than the 256 MB Infinity Cache (see cbca_strip_kernel)
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
 	// short arms (L1 <= 5, the KITTI parameter sets): every lane walks its own supports out of 9-row rings; on a Gaussian
-	// texture it is within 8 % of the strip kernel, on real-scene arm statistics 4.6 x faster
-	const bool window = cfg.form == 2 || (cfg.form == 0 && max_arm >= 0 && max_arm <= CW_ARM);
+	// texture it is within 8 % of the strip kernel, on real-scene arm statistics 4.6 x faster.  With the arm bound unknown
+	// (the standalone operator) both kernels are launched and cbca_pack's second flag word lets exactly one of them run.
+	const bool by_arm = cfg.form == 0 && max_arm < 0 && !listmem;
+	const bool window = cfg.form == 2 || (cfg.form == 0 && max_arm >= 0 && max_arm <= CW_ARM) || by_arm;
+	A.by_arm = by_arm ? 1 : 0;
 	if (window) {
-		A.gx = (int)cdiv(W, CW_STEP);
-		const int64_t gy_w = cdiv((int64_t)16384, (int64_t)A.gx * nd);
-		A.rb = cfg.rb > 0 ? cfg.rb : (int)std::min<int64_t>(40, std::max<int64_t>(16, cdiv((int64_t)H, gy_w)));
-		A.gy = (int)cdiv(H, A.rb);
-		const int64_t wv = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(nd, CW_WAVES) * CW_WAVES;
-		if (nt) hipLaunchKernelGGL((cbca_window_kernel<true>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, A);
-		else hipLaunchKernelGGL((cbca_window_kernel<false>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, A);
-		return check_launch("cbca_window");
+		CbcaArgs B = A;
+		B.gx = (int)cdiv(W, CW_STEP);
+		const int64_t gy_w = cdiv((int64_t)16384, (int64_t)B.gx * nd);
+		B.rb = cfg.rb > 0 ? cfg.rb : (int)std::min<int64_t>(40, std::max<int64_t>(16, cdiv((int64_t)H, gy_w)));
+		B.gy = (int)cdiv(H, B.rb);
+		const int64_t wv = (int64_t)cdiv((int64_t)B.gx * B.gy, 8) * 8 * cdiv(nd, CW_WAVES) * CW_WAVES;
+		if (nt) hipLaunchKernelGGL((cbca_window_kernel<true>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, B);
+		else hipLaunchKernelGGL((cbca_window_kernel<false>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, B);
+		if (!by_arm) return check_launch("cbca_window");
 	}
 	// prefetch 2 rows, ring of 4 rows, 1 row of look-ahead, window form +-2 columns (+-4 measured slower at KITTI and 1000x1500)
 	if (listmem) {
