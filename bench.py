@@ -248,7 +248,11 @@ def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None):
     if dom is None:
         return None
     achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9
-    rec = dict(bound="hbm", kernel=KERNEL_NAMES[dom], picked_by="largest measured stage time", achieved=round(achieved, 1),
+    kname = KERNEL_NAMES[dom]
+    if dom == "cbca":
+        kname = ("cbca_window_kernel" if prm["L1"] <= 5 else "cbca_strip_kernel + cbca_list_kernel (+ once-per-pair classification)") + \
+                " (one iteration over one volume per launch)"
+    rec = dict(bound="hbm", kernel=kname, picked_by="largest measured stage time", achieved=round(achieved, 1),
                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic_all.get(dom),
                launches_per_step=nl[dom], algorithmic_bytes_per_launch=round(ab[dom] / nl[dom]),
                avg_launch_ms=round(acc[dom] / nl[dom], 4), kernels=kernels,

@@ -2,7 +2,7 @@
 ulimit -c 0
 O=$GRAFT_REPO_ROOT/gpurun_out/cw; mkdir -p $O
 R=$PWD; cd /tmp; export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o cw -- python $R/scripts/gpu_cbca_dense.py 2>&1 | grep -v "amdgpu.ids\|rocprofv3\|^W2\|^E2"
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o cw -- python $R/scripts/gpu_cbca_dense.py 2>&1 | grep -v "amdgpu.ids\|rocprofv3\|^W2\|^E2" | tee $O/dense.txt
 cd $R
 python - <<'PY'
 import csv, glob

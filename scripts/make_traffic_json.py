@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """profiles/traffic_<config>.json from the PMC passes of scripts/gpu_pmc.sh: measured HBM-side bytes per LAUNCH of the
-dominant kernel groups (`sgm`: the sgm_pass_kernel launches of one step; `cbca`: cbca_strip_kernel), collected and
+dominant kernel groups (`sgm`: the sgm_pass_kernel launches of one step; `cbca`: the kernels of one iteration over one volume), collected and
 corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes, FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE x2 on
 gfx950 (128-byte requests tallied as 64 B), WRITE_SIZE at face value.
   python scripts/make_traffic_json.py gpurun_out/<tag>/pmc_<config> <config>"""
@@ -19,9 +19,11 @@ def main(d, config):
             if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean over dispatches; source: " + d}
-    groups = {"sgm": "sgm_pass_kernel", "cbca": "cbca_strip_kernel", "join": "join_owner_kernel", "transpose": "transpose_kernel"}
+    # cbca: one ITERATION over one volume = window kernel (L1 <= 5) or strip kernel + list kernel (L1 > 5): summed, not averaged
+    groups = {"sgm": ("sgm_pass_kernel",), "cbca": ("cbca_strip_kernel", "cbca_window_kernel", "cbca_list_kernel<"), "join": ("join_owner_kernel",),
+              "transpose": ("transpose_kernel",)}
     for g, pat in groups.items():
-        ks = [k for k in acc if pat in k]
+        ks = [k for k in acc if any(q in k for q in pat)]
         if not ks:
             continue
         tot, per_kernel = 0.0, {}
@@ -30,7 +32,7 @@ def main(d, config):
             wr = sum(acc[k]["WRITE_SIZE"]) / max(1, len(acc[k]["WRITE_SIZE"])) * 1024
             per_kernel[k[:90]] = dict(read=round(rd), write=round(wr))
             tot += rd + wr
-        out[g] = round(tot / len(ks))
+        out[g] = round(tot if g == "cbca" else tot / len(ks))
         out[g + "_kernels"] = per_kernel
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_%s.json" % config)
     json.dump(out, open(path, "w"), indent=1)
