@@ -650,8 +650,26 @@ __global__ void __launch_bounds__(256) cbca_list_build_kernel(const uint32_t *__
 			if (inside) bucket = (int)(int8_t)cls[id];   // 0xff -> -1
 		} else {
 			if (inside && x + sh >= 0 && x + sh < W) {
-				int size;
-				if (cbca_listed(p0, p1, y, x, sh, W, size)) bucket = cl_bucket(size);
+				// most supports reach one row up and down: the three rows' lengths are fetched together (one round trip);
+				// only taller supports walk their rows one after the other
+				const int g = y * W + x, ga = max(y - 1, 0) * W + x, gb = min(y + 1, H - 1) * W + x;
+				const uint32_t a0 = p0[ga], a1 = p1[ga + sh], o0 = p0[g], o1 = p1[g + sh], b0 = p0[gb], b1 = p1[gb + sh];
+				const uint32_t own = bytemin4(o0, o1);
+				const int u = (int)((own >> 16) & 0xff), dn = (int)(own >> 24);
+				if (u <= 1 && dn <= 1) {
+					const uint32_t ma = bytemin4(a0, a1), mb = bytemin4(b0, b1);
+					auto lr = [](uint32_t m, int &l, int &r) { l = (int)(m & 0xff); r = (int)((m >> 8) & 0xff); };
+					int l, r, n;
+					lr(own, l, r);
+					bool fits = l <= 2 && r <= 2;
+					n = l + r + 1;
+					if (u == 1) { lr(ma, l, r); fits = fits && l <= 2 && r <= 2; n += l + r + 1; }
+					if (dn == 1) { lr(mb, l, r); fits = fits && l <= 2 && r <= 2; n += l + r + 1; }
+					if (!fits) bucket = cl_bucket(n);
+				} else {
+					int size;
+					if (cbca_listed(p0, p1, y, x, sh, W, size)) bucket = cl_bucket(size);
+				}
 			}
 			if (inside) cls[id] = (uint8_t)bucket;
 		}
@@ -782,7 +800,9 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const CbcaListEntry *__r
 			// 16 floats from the run's start stay inside the volume (the last rows of the last plane take the exact path)
 			const bool whole = n <= 16 && vbase + (uint32_t)ro + 16u <= nvox;
 			if (whole) {
-				const cl_f4u v0 = *(const cl_f4u *)row, v1 = *(const cl_f4u *)(row + 4);
+				const cl_f4u v0 = *(const cl_f4u *)row;
+				cl_f4u v1 = cl_f4u{0.0f, 0.0f, 0.0f, 0.0f};
+				if (n > 4) v1 = *(const cl_f4u *)(row + 4);   // (a lane whose run ends inside the first 16 bytes issues no second access)
 				const float a[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
 				for (int t = 0; t < 8; ++t) sum += t < n ? a[t] : -0.0f;   // x + (-0.0f) == x: the values behind the run are no operands

@@ -73,3 +73,25 @@ def test_fused_predict_at_benchmarked_shape(ref, mc, config):
     for k in ("dispL0", "dispR0"):
         d = want[k]
         assert float(d.min()) >= 0 and float(d.max()) <= D - 1 and bool((d == d.round()).all())
+
+
+@pytest.mark.parametrize("preset,H,W,D", [("mb_slow", 260, 700, 48), ("kitti2015_slow", 200, 640, 64), ("mb_census", 130, 500, 40)])
+def test_fused_predict_on_real_scene_arm_statistics(ref, mc, preset, H, W, D):
+    """the regime real images are in (tests/util.natural_pair): cbca by window kernel (L1 <= 5) / strip kernel + the
+    pair's list of large supports (L1 > 5), both aggregation blocks, through mc_predict, against the reference's kernels"""
+    from ref_pipeline import ref_stereo_predict
+    from mc_cnn_amd.predict import Workspace
+    from util import natural_pair, raw_volumes
+    prm = dict(mc.PRESETS[preset])
+    device = torch.device("cuda", 0)
+    x0, x1 = natural_pair(H, W, D, seed=7, sigma=25.0)
+    xb = torch.from_numpy(np.stack([x0, x1])[:, None]).to(device)
+    vl, vr = raw_volumes(D, H, W, seed=11)
+    kw = dict(raw=(torch.from_numpy(vl).to(device), torch.from_numpy(vr).to(device)))
+    ws = Workspace(prm, D, H, W, device)
+    got = mc.stereo_predict_fused(xb, prm, D, workspace=ws, want_volumes=True, want_disp0=True, **kw)
+    torch.cuda.synchronize()
+    want = ref_stereo_predict(ref, prm, xb, D, **kw)
+    torch.cuda.synchronize()
+    for key, label in (("volL", "left.bin"), ("volR", "right.bin"), ("dispL0", "left argmin"), ("dispR0", "right argmin"), ("disp", "disp.bin")):
+        assert_same_bits_dev(got[key], want[key], "%s %s on the realistic pair" % (preset, label))
