@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 // 370x1226x228 against 0.8 ms on a Gaussian texture.
 //
 // Here a wave owns a plane, a strip of 256 staged columns (248 outputs, +-4 halo) and RB rows; rings of 9 rows (values,
-// nibble-packed minimum arm lengths) cover every support of the output row 4 rows behind the newest one.  A lane owns four
+// run masks of the minimum arm lengths) cover every support of the output row 4 rows behind the newest one.  A lane owns four
 // adjacent outputs.  Per support row it reads its 12-column window once (3 x ds_read_b128) and, per output, turns the
 // row's (left, right) into a 9-bit run mask; each of the 9 taps is then  sum += bit ? value : -0.0f  as v_bfe_i32 +
 // v_bfi_b32 + v_add_f32.  x + (-0.0f) == x exactly and a value that is not selected is never an operand, so the chain of
@@ -461,8 +461,14 @@ __global__ void __launch_bounds__(64 * CW_WAVES) cbca_window_kernel(const CbcaAr
 		st.a = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
 		st.b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
 	};
-	// lengths (left, right, up, down) as four nibbles: every arm this kernel is launched for is <= CW_ARM
-	auto nib = [](cb_u32 m) -> cb_u32 { return (m & 0xfu) | ((m >> 4) & 0xf0u) | ((m >> 8) & 0xf00u) | ((m >> 12) & 0xf000u); };
+	// per column 16 bits: the row's 9-bit RUN MASK (bit k <-> column offset k - 4 belongs to the run: it depends on the
+	// row's left / right lengths only, so it is built once per row here and not once per output row that uses it), up in
+	// bits 9..11, down in bits 12..14 (every arm this kernel is launched for is <= CW_ARM = 4)
+	auto nib = [](cb_u32 m) -> cb_u32 {
+		const cb_u32 l = m & 0xffu, r = (m >> 8) & 0xffu, u = (m >> 16) & 0xffu, d = m >> 24;
+		const cb_u32 run = ((1u << (l + r + 1u)) - 1u) << (CW_ARM - l);
+		return (run & 0x1ffu) | ((u & 7u) << 9) | ((d & 7u) << 12);
+	};
 	auto commit = [&](const Stage &st, int slot) {
 		*(cb_u4 *)(Vw + slot * CW_VPITCH + 4 + 4 * lane) = st.v;
 		const cb_u32 m0 = nib(bytemin4(st.a.x, st.b.x)), m1 = nib(bytemin4(st.a.y, st.b.y));
@@ -475,13 +481,13 @@ __global__ void __launch_bounds__(64 * CW_WAVES) cbca_window_kernel(const CbcaAr
 		int s0 = rs + (CW_RING - CW_ARM);
 		s0 = s0 >= CW_RING ? s0 - CW_RING : s0;
 		const cb_u2 mo = *(const cb_u2 *)(Mw + s0 * CS_COLS + 4 * lane);
-		const cb_u32 ud[4] = {(mo.x >> 8) & 0xffu, mo.x >> 24, (mo.y >> 8) & 0xffu, mo.y >> 24};   // up | down << 4
+		const cb_u32 ud[4] = {(mo.x >> 9) & 0x3fu, mo.x >> 25, (mo.y >> 9) & 0x3fu, mo.y >> 25};   // up | down << 3
 		int up[4], dn[4], umax = 0, dmax = 0;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const bool take = exists[j] && inr[j];
-			up[j] = take ? (int)(ud[j] & 0xfu) : -1;
-			dn[j] = take ? (int)(ud[j] >> 4) : -1;
+			up[j] = take ? (int)(ud[j] & 7u) : -1;
+			dn[j] = take ? (int)((ud[j] >> 3) & 7u) : -1;
 			umax = max(umax, up[j]);
 			dmax = max(dmax, dn[j]);
 		}
@@ -504,7 +510,7 @@ __global__ void __launch_bounds__(64 * CW_WAVES) cbca_window_kernel(const CbcaAr
 			const cb_f4 q0 = *(const cb_f4 *)vr, q1 = *(const cb_f4 *)(vr + 4), q2 = *(const cb_f4 *)(vr + 8);
 			const float v[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 			const cb_u2 mr = *(const cb_u2 *)(Mw + sl * CS_COLS + 4 * lane);
-			const cb_u32 mrow[4] = {mr.x, mr.x >> 16, mr.y, mr.y >> 16};   // low byte: left | right << 4
+			const cb_u32 mrow[4] = {mr.x, mr.x >> 16, mr.y, mr.y >> 16};   // low 9 bits: the row's run mask
 			if (rel == 0) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) own[j] = v[4 + j];
@@ -514,9 +520,7 @@ __global__ void __launch_bounds__(64 * CW_WAVES) cbca_window_kernel(const CbcaAr
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				const int need = rel < 0 ? up[j] : dn[j];
-				const cb_u32 l = mrow[j] & 0xfu, r = (mrow[j] >> 4) & 0xfu;
-				const cb_u32 run = ((1u << (l + r + 1u)) - 1u) << (CW_ARM - l);   // bit k <-> column offset k - 4
-				mask[j] = need >= arel ? run : 0u;
+				mask[j] = need >= arel ? (mrow[j] & 0x1ffu) : 0u;
 				cnt[j] += __builtin_popcount(mask[j]);
 				anywide |= mask[j];
 			}
