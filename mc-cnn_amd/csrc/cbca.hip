@@ -643,25 +643,57 @@ __global__ void __launch_bounds__(256) cbca_list_build_kernel(const uint32_t *__
 	const int64_t tiles = (int64_t)tx * ty * D;
 	const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
 	const int64_t t0 = per * blockIdx.x, t1 = min(tiles, t0 + per);
+	// what a tile row needs from memory is fetched one tile ahead: the loop is a chain of round trips otherwise (a block
+	// walks ~750 tiles one after the other)
+	struct Pre {
+		int x, y, sh;
+		bool inside, valid;
+		uint32_t id;
+		uint32_t a0, a1, o0, o1, b0, b1;   // count pass: lengths of rows y-1, y, y+1 in both images
+		int cls;                           // fill pass: the class byte
+	};
+	// tile coordinates advance by counters (a 64-bit division per tile was most of the kernel's instructions)
+	int fbx = (int)(t0 % tx), fby = (int)((t0 / tx) % ty), fd = (int)(t0 / ((int64_t)tx * ty));
+	auto fetch = [&](int64_t t) -> Pre {
+		Pre q;
+		const int bx = fbx, by = fby, d = fd;
+		if (++fbx == tx) {
+			fbx = 0;
+			if (++fby == ty) { fby = 0; ++fd; }
+		}
+		q.x = bx * 64 + lane; q.y = by * 4 + wv;
+		q.sh = d * direction;
+		q.inside = t < t1 && q.x < W && q.y < H;
+		q.valid = q.inside && q.x + q.sh >= 0 && q.x + q.sh < W;
+		q.id = (uint32_t)((d * H + q.y) * W + q.x);
+		q.a0 = q.a1 = q.o0 = q.o1 = q.b0 = q.b1 = 0;
+		q.cls = -1;
+		if (FILL) {
+			if (q.inside) q.cls = (int)(int8_t)cls[q.id];   // 0xff -> -1
+		} else if (q.valid) {
+			const int g = q.y * W + q.x, ga = max(q.y - 1, 0) * W + q.x, gb = min(q.y + 1, H - 1) * W + q.x;
+			q.a0 = p0[ga]; q.a1 = p1[ga + q.sh]; q.o0 = p0[g]; q.o1 = p1[g + q.sh]; q.b0 = p0[gb]; q.b1 = p1[gb + q.sh];
+		}
+		return q;
+	};
+	Pre nxt = fetch(t0);
 	for (int64_t t = t0; t < t1; ++t) {
-		const int bx = (int)(t % tx), by = (int)((t / tx) % ty), d = (int)(t / ((int64_t)tx * ty));
-		const int x = bx * 64 + lane, y = by * 4 + wv;
-		const int sh = d * direction;
-		const bool inside = x < W && y < H;
-		const uint32_t id = (uint32_t)((d * H + y) * W + x);
+		const Pre c = nxt;
+		nxt = fetch(t + 1);
+		const int x = c.x, y = c.y, sh = c.sh;
+		const bool inside = c.inside;
+		const uint32_t id = c.id;
 		int bucket = -1;
 		if (FILL) {
-			if (inside) bucket = (int)(int8_t)cls[id];   // 0xff -> -1
+			bucket = c.cls;
 		} else {
-			if (inside && x + sh >= 0 && x + sh < W) {
-				// most supports reach one row up and down: the three rows' lengths are fetched together (one round trip);
-				// only taller supports walk their rows one after the other
-				const int g = y * W + x, ga = max(y - 1, 0) * W + x, gb = min(y + 1, H - 1) * W + x;
-				const uint32_t a0 = p0[ga], a1 = p1[ga + sh], o0 = p0[g], o1 = p1[g + sh], b0 = p0[gb], b1 = p1[gb + sh];
-				const uint32_t own = bytemin4(o0, o1);
+			if (c.valid) {
+				// most supports reach one row up and down: the three rows' lengths were fetched together; only taller
+				// supports walk their rows one after the other
+				const uint32_t own = bytemin4(c.o0, c.o1);
 				const int u = (int)((own >> 16) & 0xff), dn = (int)(own >> 24);
 				if (u <= 1 && dn <= 1) {
-					const uint32_t ma = bytemin4(a0, a1), mb = bytemin4(b0, b1);
+					const uint32_t ma = bytemin4(c.a0, c.a1), mb = bytemin4(c.b0, c.b1);
 					auto lr = [](uint32_t m, int &l, int &r) { l = (int)(m & 0xff); r = (int)((m >> 8) & 0xff); };
 					int l, r, n;
 					lr(own, l, r);

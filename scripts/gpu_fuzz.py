@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import mc_cnn_amd as mc
 from oracle import cpu_oracle as oracle
-from util import smooth_pair, blocky_pair, random_pair, features, raw_volumes  # noqa: E402
+from util import smooth_pair, blocky_pair, random_pair, natural_pair, features, raw_volumes  # noqa: E402
 
 from util import same_bits as same
 
@@ -29,8 +29,11 @@ for it in range(n):
         prm["sm_terminate"] = ["", "cnn", "cbca1", "sgm", "cbca2", "subpixel_enchancement", "median", "bilateral"][rng.integers(8)]
     if rng.random() < 0.3:
         prm["sm_skip"] = ["", "cbca", "sgm", "occlusion", "subpixel_enchancement", "median", "bilateral"][rng.integers(7)]
-    kind = ["smooth", "blocky", "random"][rng.integers(3)]
+    kind = ["smooth", "blocky", "random", "natural", "natural"][rng.integers(5)]
+    if rng.random() < 0.25:   # arm limits between the parameter tables' (window kernel / strip + list boundary at L1 = 5 | 6)
+        prm["L1"] = int(rng.integers(0, 20)); prm["tau1"] = float(rng.choice([0.02, 0.13, 0.5, 3.0]))
     x0, x1 = (smooth_pair(H, W, min(D, 8), seed=it) if kind == "smooth" else blocky_pair(H, W, seed=it) if kind == "blocky"
+              else natural_pair(H, W, min(D, 8), seed=it, sigma=float(rng.choice([6.0, 15.0, 40.0]))) if kind == "natural"
               else random_pair(H, W, seed=it))
     xb = torch.from_numpy(np.stack([x0, x1])).cuda()[:, None]
     from_feat = rng.random() < 0.5
@@ -50,7 +53,7 @@ for it in range(n):
     fails = [k for k in ("volL", "volR", "dispL0", "dispR0", "disp") if not same(got[k].cpu().numpy(), want[k])]
     if fails:
         bad += 1
-        print("MISMATCH", fails, dict(name=name, H=H, W=W, D=D, C=C, kind=kind, sm_terminate=prm.get("sm_terminate"), sm_skip=prm.get("sm_skip"),
+        print("MISMATCH", fails, dict(name=name, H=H, W=W, D=D, C=C, kind=kind, L1=prm["L1"], tau1=prm["tau1"], sm_terminate=prm.get("sm_terminate"), sm_skip=prm.get("sm_skip"),
                                       border_n=prm.get("border_n")), flush=True)
 print("fuzz: %d cases, %d mismatching, %.0f s" % (n, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
