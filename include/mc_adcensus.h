@@ -108,10 +108,14 @@ int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_
 
 /* The same operator on the fast path: the per-arm minimum lengths of the two images are packed into `scratch`
  * (mc_cbca_scratch_bytes, 4 bytes per pixel and image) and one wave walks a strip of 256 staged columns of one
- * disparity plane top to bottom (rows in registers / a wave-private LDS ring, no block barrier); same accumulation
- * order, bit-identical to mc_cbca.  Supports that leave the staged rows or columns are summed from global memory by
- * the same wave; an arm longer than 254 pixels (not representable in the packed form) makes the call fall back to
- * mc_cbca's kernel inside the same call. */
+ * disparity plane top to bottom (rows in registers / wave-private LDS rings, no block barrier); same accumulation
+ * order, bit-identical to mc_cbca.  Two kernels are launched and the packing pass lets exactly one run: no arm longer
+ * than 4 (arms from mc_cross with L1 <= 5) -> the window kernel, every lane walks the supports of its four outputs out
+ * of 9-row rings (real scenes: most supports are larger than 3x3); otherwise the strip kernel, minimal 3x3 supports
+ * out of registers, the others compacted per row (from the rings where they fit, from global memory otherwise).  An arm
+ * longer than 254 pixels (not representable in the packed form) makes the call fall back to mc_cbca's kernel inside
+ * the same call.  (mc_predict knows L1 and launches one kernel; for L1 > 5 it also classifies the pair's supports
+ * once into a list sorted by size, which a third kernel walks -- see mc_cbca_ws_cfg, form 3.) */
 size_t mc_cbca_scratch_bytes(int H, int W);
 int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
                int D, int H, int W, int direction, void *scratch, size_t scratch_bytes, void *stream);
@@ -217,7 +221,8 @@ enum { MC_SM_NONE = 0, MC_SM_CNN = 1, MC_SM_CBCA1 = 2, MC_SM_SGM = 3, MC_SM_CBCA
 enum { MC_SKIP_NONE = 0, MC_SKIP_CBCA = 1, MC_SKIP_SGM = 2, MC_SKIP_OCCLUSION = 3, MC_SKIP_SUBPIXEL = 4,
        MC_SKIP_MEDIAN = 5, MC_SKIP_BILATERAL = 6 };
 
-/* Workspace bytes mc_predict needs for the given problem. */
+/* Workspace bytes mc_predict needs for the given problem: six volumes, six maps, the SGM edge classes, arms and packed
+ * arm lengths; with cross-based aggregation and L1 > 5 also two lists of supports (17 bytes per voxel each). */
 size_t mc_predict_workspace_bytes(const mc_params *p, int C, int D, int H, int W);
 
 /* stereo_predict(x_batch, id), main.lua:929-1082, from the cost-volume stage on.

@@ -128,8 +128,13 @@ __global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict_
 // re-runs the reference's loop (rows ascending, x ascending, one accumulator) for list entry i -- out of the ring where
 // the support lies inside rows y-2..y+1 / the strip's 256 columns and out of global memory otherwise -- and patches
 // the row of results in LDS before it is stored.
-// CS_RING rows per ring, CS_LA rows committed below (and staged above) the current output row, CS_WR column radius of
-// the window form
+// This is the kernel for images on which nearly every support is the minimal 3x3 (Gaussian textures: bandwidth-bound).
+// On real scenes most supports are larger and a pass runs at the pace of its largest one: there the window kernel
+// (arms <= 4) or, for longer arms, the LISTED instantiation takes over -- the supports that do not fit the window form by
+// their SHAPE are then skipped here (the value stored for them is provisional) and come from the pair's list
+// (cbca_list_kernel, launched after this kernel on the same stream).
+// CS_RING rows per ring, CS_LA rows committed below the current output row (two rows are staged above the first output
+// row of a chunk: the window form reaches two rows up), CS_WR column radius of the window form
 template <int PF, int CS_RING, int CS_LA, int CS_WR, bool NT, bool LISTED>
 __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 {
