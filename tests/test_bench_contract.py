@@ -62,3 +62,12 @@ def test_gpus_n_without_a_launcher_spawns_its_own_ranks():
     assert 'if args.gpus > 1 and "WORLD_SIZE" not in os.environ:' in src and "spawn_ranks(args.gpus)" in src
     assert "ranks_seen" in src and "gathered_equals_single_gpu" in src
     assert '"verify": verify' in src and '"north_star": north' in src
+
+
+def test_every_config_names_its_image_pair():
+    """the pair decides the cost of cbca: KITTI shapes on the realistic pair, 1000x1500 on the specified texture"""
+    b = _bench() if "_bench" in globals() else __import__("bench")
+    assert set(b.PAIR_OF) == set(b.CONFIGS)
+    assert all(v in b.PAIR_NOTE for v in b.PAIR_OF.values())
+    assert b.PAIR_OF["kitti_fast"] == b.PAIR_OF["kitti_slow"] == "natural" and b.PAIR_OF["mb_slow"] == "texture"
+    assert b.config_key(b.CONFIGS["kitti_slow_fc"]) == "kitti_slow_fc"
