@@ -231,7 +231,41 @@ def copy_rate(device, nbytes):
     return _COPY_RATE[key]
 
 
-def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None):
+FP32_ADD_PEAK = 256 * 64 * 2.4e9   # scalar v_add_f32: 256 CUs x 64 lanes per cycle (4 SIMDs x 16) x 2.4 GHz = 39.3 T additions/s
+
+
+def cbca_additions(xb, prm, D, n_planes=8):
+    """What bounds cross-based aggregation when the supports are large: every output is ONE serial chain of additions (the
+    reference's summation order), as many as its support has taps.  Mean support size of the LEFT volume (direction -1),
+    sampled at n_planes disparities, from the arms the product's own `cross` computes for this pair (adcensus.cu:280-322,
+    343-377: the support is the per-arm minimum over the two images, rows y-up .. y+down, columns x-left .. x+right)."""
+    import torch
+    import mc_cnn_amd as mc
+    H, W = xb.shape[-2:]
+    arms = []
+    for i in range(2):
+        c = torch.empty((1, 4, H, W), dtype=torch.float32, device=xb.device)
+        mc.adcensus.cross(xb[i:i + 1], c, prm["L1"], prm["tau1"])
+        c = c[0].cpu().numpy()
+        xs, ys = np.arange(W)[None, :], np.arange(H)[:, None]
+        arms.append(np.stack([xs - c[0] - 1, c[1] - xs - 1, ys - c[2] - 1, c[3] - ys - 1]).astype(np.int64))
+    aL, aR = arms
+    taps = vox = 0
+    ys = np.arange(H)[:, None]
+    for d in sorted({int(round(k * (D - 1) / max(1, n_planes - 1))) for k in range(n_planes)}):
+        if d >= W:
+            continue
+        l, r, u, dn = np.minimum(aL[:, :, d:], aR[:, :, :W - d] if d else aR)   # left pixel x pairs with right pixel x - d
+        rowlen = l + r + 1
+        cs = np.vstack([np.zeros((1, rowlen.shape[1]), np.int64), np.cumsum(rowlen, 0)])
+        cols = np.arange(rowlen.shape[1])[None, :]
+        size = cs[np.clip(ys + dn + 1, 0, H), cols] - cs[np.clip(ys - u, 0, H), cols]
+        taps += int(size.sum())
+        vox += size.size
+    return taps / max(1, vox)
+
+
+def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None, xb=None):
     ab = algorithmic_bytes(prm, H, W, D, max(C, 0))
     nl = launches_per_step(prm, max(C, 0))
     traffic_all = {}
@@ -257,6 +291,15 @@ def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None):
                launches_per_step=nl[dom], algorithmic_bytes_per_launch=round(ab[dom] / nl[dom]),
                avg_launch_ms=round(acc[dom] / nl[dom], 4), kernels=kernels,
                pipeline_frac=round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    if xb is not None and "cbca" in kernels:
+        try:  # the compute side of cbca: serial additions per voxel on THIS pair
+            apv = cbca_additions(xb, prm, D)
+            adds = apv * 2.0 * D * H * W * (prm["cbca_i1"] + prm["cbca_i2"])   # both volumes, all iterations (NaN-triangle voxels are copies: slight overcount)
+            kernels["cbca"].update(additions_per_voxel=round(apv, 2), additions_T_per_s=round(adds / (acc["cbca"] * 1e-3) / 1e12, 3),
+                                   frac_of_fp32_add_peak=round(adds / (acc["cbca"] * 1e-3) / FP32_ADD_PEAK, 4),
+                                   additions_note="mean support size of the left volume at 8 disparities; peak = 39.3 T scalar fp32 additions/s")
+        except Exception as e:  # never lose the bench line over a side figure
+            kernels["cbca"]["additions_error"] = str(e)[:200]
     if device is not None:  # the same figures against what a plain copy of one volume reaches on THIS box
         cr = copy_rate(device, 4 * D * H * W)
         rec["box_copy"] = dict(GBs=round(cr, 1), working_set_bytes=2 * 4 * D * H * W, frac_of_peak=round(cr / HBM_PEAK_GBS, 4),
@@ -303,7 +346,7 @@ def north_star_record(device, steps=5):
                                frac_of_hbm_peak=round(budget / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                frac_incl_layout=round(budget / ((sweep_ms + layout_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                target=0.70),
-               roofline=roofline_record("mb_slow", prm, H, W, D, C, acc, ms, device),
+               roofline=roofline_record("mb_slow", prm, H, W, D, C, acc, ms, device, xb),
                verify=verify_against_reference(cfg, xb, kw, prm, D, ws, "mb_slow"))
     del ws, xb, kw
     torch.cuda.empty_cache()
@@ -334,8 +377,15 @@ def north_star_realistic(device):
     step()
     acc = stage_times(step, 1)
     n_it = prm["cbca_i1"] + prm["cbca_i2"]
+    try:
+        apv = cbca_additions(xb, prm, D)
+    except Exception:  # a side figure must not cost the record
+        apv = float("nan")
+    adds = apv * 2.0 * D * H * W * n_it
     rec = dict(pair=PAIR_NOTE["natural"], ms_per_pair=round(sum(acc.values()), 2), stage_ms={k: round(v, 3) for k, v in acc.items()},
-               cbca_ms_per_launch=round(acc.get("cbca", 0) / (2 * n_it), 3),
+               cbca_ms_per_launch=round(acc.get("cbca", 0) / (2 * n_it), 3), cbca_additions_per_voxel=round(apv, 2),
+               cbca_additions_T_per_s=round(adds / (acc["cbca"] * 1e-3) / 1e12, 3),
+               cbca_frac_of_fp32_add_peak=round(adds / (acc["cbca"] * 1e-3) / FP32_ADD_PEAK, 4),
                verify=verify_against_reference(cfg, xb, kw, prm, D, ws, "mb_slow"))
     del ws, xb, kw
     torch.cuda.empty_cache()
@@ -503,7 +553,7 @@ def main():
                 acc["fc_stack"] = acc.get("fc_stack", 0.0) + e0.elapsed_time(e1) / reps
         acc.update(stage_times(step, reps))
         stage = {k: round(v, 4) for k, v in acc.items()}
-        roof = roofline_record(args.config, prm, H, W, D, C, acc, ms_per_step, device)
+        roof = roofline_record(args.config, prm, H, W, D, C, acc, ms_per_step, device, xb)
 
     if rank == 0 and fc_ws is not None and roof is not None:
         # the accurate net's dominant kernel is the FC stack: a dense fp32 GEMM chain on the matrix cores
