@@ -234,11 +234,30 @@ def copy_rate(device, nbytes):
 FP32_ADD_PEAK = 256 * 64 * 2.4e9   # scalar v_add_f32: 256 CUs x 64 lanes per cycle (4 SIMDs x 16) x 2.4 GHz = 39.3 T additions/s
 
 
+def arm_lengths(ends):
+    """cross's exclusive arm ends (4,H,W) (adcensus.cu:280-322) -> lengths (left, right, up, down) as integers"""
+    c = np.asarray(ends, np.float64).reshape(4, *np.shape(ends)[-2:])
+    H, W = c.shape[1:]
+    xs, ys = np.arange(W)[None, :], np.arange(H)[:, None]
+    return np.stack([xs - c[0] - 1, c[1] - xs - 1, ys - c[2] - 1, c[3] - ys - 1]).astype(np.int64)
+
+
+def support_sizes(aL, aR, d):
+    """tap count of every support of the LEFT volume's plane d (adcensus.cu:343-377, direction -1: left pixel x pairs with
+    right pixel x - d): per-arm minimum of the two images, rows y-up .. y+down, in each row columns x-left .. x+right.
+    Returns an (H, W-d) array for the columns x >= d (the others are copied through)."""
+    H, W = aL.shape[1:]
+    l, r, u, dn = np.minimum(aL[:, :, d:], aR[:, :, :W - d] if d else aR)
+    rowlen = l + r + 1
+    cs = np.vstack([np.zeros((1, rowlen.shape[1]), np.int64), np.cumsum(rowlen, 0)])
+    ys, cols = np.arange(H)[:, None], np.arange(rowlen.shape[1])[None, :]
+    return cs[np.clip(ys + dn + 1, 0, H), cols] - cs[np.clip(ys - u, 0, H), cols]
+
+
 def cbca_additions(xb, prm, D, n_planes=8):
     """What bounds cross-based aggregation when the supports are large: every output is ONE serial chain of additions (the
-    reference's summation order), as many as its support has taps.  Mean support size of the LEFT volume (direction -1),
-    sampled at n_planes disparities, from the arms the product's own `cross` computes for this pair (adcensus.cu:280-322,
-    343-377: the support is the per-arm minimum over the two images, rows y-up .. y+down, columns x-left .. x+right)."""
+    reference's summation order), as many as its support has taps.  Mean support size of the left volume, sampled at
+    n_planes disparities, from the arms the product's own `cross` computes for this pair."""
     import torch
     import mc_cnn_amd as mc
     H, W = xb.shape[-2:]
@@ -246,22 +265,13 @@ def cbca_additions(xb, prm, D, n_planes=8):
     for i in range(2):
         c = torch.empty((1, 4, H, W), dtype=torch.float32, device=xb.device)
         mc.adcensus.cross(xb[i:i + 1], c, prm["L1"], prm["tau1"])
-        c = c[0].cpu().numpy()
-        xs, ys = np.arange(W)[None, :], np.arange(H)[:, None]
-        arms.append(np.stack([xs - c[0] - 1, c[1] - xs - 1, ys - c[2] - 1, c[3] - ys - 1]).astype(np.int64))
-    aL, aR = arms
+        arms.append(arm_lengths(c[0].cpu().numpy()))
     taps = vox = 0
-    ys = np.arange(H)[:, None]
     for d in sorted({int(round(k * (D - 1) / max(1, n_planes - 1))) for k in range(n_planes)}):
-        if d >= W:
-            continue
-        l, r, u, dn = np.minimum(aL[:, :, d:], aR[:, :, :W - d] if d else aR)   # left pixel x pairs with right pixel x - d
-        rowlen = l + r + 1
-        cs = np.vstack([np.zeros((1, rowlen.shape[1]), np.int64), np.cumsum(rowlen, 0)])
-        cols = np.arange(rowlen.shape[1])[None, :]
-        size = cs[np.clip(ys + dn + 1, 0, H), cols] - cs[np.clip(ys - u, 0, H), cols]
-        taps += int(size.sum())
-        vox += size.size
+        if d < W:
+            size = support_sizes(arms[0], arms[1], d)
+            taps += int(size.sum())
+            vox += size.size
     return taps / max(1, vox)
 
 

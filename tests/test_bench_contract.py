@@ -71,3 +71,21 @@ def test_every_config_names_its_image_pair():
     assert all(v in b.PAIR_NOTE for v in b.PAIR_OF.values())
     assert b.PAIR_OF["kitti_fast"] == b.PAIR_OF["kitti_slow"] == "natural" and b.PAIR_OF["mb_slow"] == "texture"
     assert b.config_key(b.CONFIGS["kitti_slow_fc"]) == "kitti_slow_fc"
+
+
+def test_support_sizes_count_the_taps_of_the_reference_loop(oracle):
+    """bench's `additions_per_voxel`: the closed form against a literal walk of adcensus.cu:356-373 on the oracle's arms"""
+    import numpy as np
+    from util import natural_pair
+    b = __import__("bench")
+    H, W = 30, 70
+    x0, x1 = natural_pair(H, W, 8, seed=3, sigma=8.0)
+    aL, aR = b.arm_lengths(oracle.cross(x0, 14, 0.05)), b.arm_lengths(oracle.cross(x1, 14, 0.05))
+    for d in (0, 5):
+        size = b.support_sizes(aL, aR, d)
+        m = np.minimum(aL[:, :, d:], aR[:, :, :W - d] if d else aR)
+        for y in range(0, H, 3):
+            for x in range(0, W - d, 5):
+                l, r, u, dn = m[:, y, x]
+                want = sum(int(m[0, q, x] + m[1, q, x] + 1) for q in range(y - u, y + dn + 1))
+                assert size[y, x] == want
