@@ -39,6 +39,8 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
                      int direction, hipStream_t st);
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg(), const void *listmem = nullptr);
+int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int gate,
+               hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
 size_t cbca_list_bytes(int D, int H, int W);
 int cbca_list_build(const void *packed, void *listmem, int D, int H, int W, int direction, hipStream_t st);
 size_t conv3x3_workspace_bytes(int Cin, int Cout);
@@ -581,13 +583,15 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
 	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws_cfg: image too large for 32-bit plane offsets");
-	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 3, "mc_cbca_ws_cfg: bad rb / nt / form");
+	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 5, "mc_cbca_ws_cfg: bad rb / nt / form");
 	MC_REQUIRE(d0 >= 0 && nd >= 0 && d0 + nd <= D, "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
 	CbcaCfg cfg;
 	cfg.rb = rb; cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd; cfg.form = form == 3 ? 1 : form;
+	if (form >= 4)   // tile kernel, short-arm (4) / long-arm (5) instance; stands down (nothing written) if an arm exceeds 4 / 13
+		return cbca_tiles(scratch, vol_in, vol_out, D, H, W, direction, form == 4 ? 4 : 13, form == 4 ? 1 : 4, st, cfg);
 	const void *listmem = nullptr;
 	if (form == 3) {  // strip kernel + list kernel (what mc_predict runs for L1 > 5): the list lives behind the packed lengths
 		MC_REQUIRE(d0 == 0 && nd == 0, "mc_cbca_ws_cfg: form 3 processes whole volumes");

@@ -110,7 +110,8 @@ __global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict_
 	auto sat = [](int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
 	packed[id] = sat(l) | (sat(r) << 8) | (sat(u) << 16) | (sat(d) << 24);
 	if (overflow && (l > 254 || r > 254 || u > 254 || d > 254)) atomicOr(overflow, 1u);
-	if (overflow && (l > 4 || r > 4 || u > 4 || d > 4)) atomicOr(overflow + 1, 1u);   // an arm the window kernel does not cover
+	if (overflow && (l > 4 || r > 4 || u > 4 || d > 4)) atomicOr(overflow + 1, 1u);   // an arm beyond the short-arm kernels (L1 <= 5)
+	if (overflow && (l > 13 || r > 13 || u > 13 || d > 13)) atomicOr(overflow + 2, 1u);   // an arm beyond the tile kernel's long-arm instance (L1 <= 14)
 }
 
 // =====================================================================================================
@@ -935,14 +936,14 @@ int cbca_list_build(const void *packed, void *listmem, int D, int H, int W, int 
 	return check_launch("cbca_list_build");
 }
 
-size_t cbca_scratch_bytes(int H, int W) { return (((size_t)2 * H * W + 3 * CS_PAD + 2) * sizeof(uint32_t) + 255) & ~(size_t)255; }
+size_t cbca_scratch_bytes(int H, int W) { return (((size_t)2 * H * W + 3 * CS_PAD + CS_FLAGS) * sizeof(uint32_t) + 255) & ~(size_t)255; }
 
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st)
 {
 	const CbcaScratch cs = cbca_scratch(scratch, H, W);
 	uint32_t *p0 = cs.p0, *p1 = cs.p1, *flag = cs.flag;
 	const int64_t HW = (int64_t)H * W;
-	const hipError_t e = hipMemsetAsync(flag, 0, 2 * sizeof(uint32_t), st);
+	const hipError_t e = hipMemsetAsync(flag, 0, CS_FLAGS * sizeof(uint32_t), st);
 	if (e != hipSuccess) {
 		set_error("cbca_pack: %s", hipGetErrorString(e));
 		return (int)e;

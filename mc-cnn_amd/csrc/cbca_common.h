@@ -27,7 +27,7 @@ struct CbcaArgs {
 	float *vout;
 	int D, H, W, direction;
 	int rb;                       // output rows per strip
-	const uint32_t *overflow;     // optional, cbca_pack's flags: [0] an arm saturated the packed form -> do nothing; [1] an arm > 4
+	const uint32_t *overflow;     // optional, cbca_pack's flags: [0] an arm saturated the packed form -> do nothing; [1] an arm > 4; [2] an arm > 13
 	int by_arm;                   // 1: flag [1] selects the kernel (window kernel iff no arm > 4, strip kernel otherwise)
 	int gx, gy;                   // strips per row, row chunks
 	int d0, nd;                   // planes [d0, d0 + nd) of the volume are processed by this launch
@@ -39,7 +39,9 @@ constexpr int CS_COLS = 256;
 constexpr int CS_STEP = 252;   // output columns per strip
 constexpr int CS_PAD = 1024;   // words of padding around p0 / p1 in the scratch (shifted dwordx4 reads may start outside)
 
-// scratch = [pad | p0 (H*W) | pad | p1 (H*W) | pad | two flag words], pad = CS_PAD words
+constexpr int CS_FLAGS = 4;    // flag words behind the packed lengths (three used)
+
+// scratch = [pad | p0 (H*W) | pad | p1 (H*W) | pad | CS_FLAGS flag words], pad = CS_PAD words
 size_t cbca_scratch_bytes(int H, int W);   // cbca.hip
 
 struct CbcaScratch { uint32_t *p0, *p1, *flag; };

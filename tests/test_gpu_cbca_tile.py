@@ -1,0 +1,108 @@
+"""-m gpu: the LDS-tile kernel of cross-based aggregation (cbca forms 4 / 5 of the hook: short-arm instance, arms <= 4, and
+long-arm instance, arms <= 13 -- what mc_predict runs for L1 <= 5 / L1 <= 14) against the oracle, bit for bit: every kind of
+arm statistics, tiles with ragged edges (H, W not multiples of the tile), images smaller than one tile, both directions, both
+cache policies, plane sub-ranges, special values inside the valid region."""
+import numpy as np
+import pytest
+
+from util import blocky_pair, diff_report, natural_pair, random_pair, raw_volumes, same_bits, smooth_pair
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def pair(mk, H, W, D):
+    return {"smooth": lambda: smooth_pair(H, W, 8, seed=H), "random": lambda: random_pair(H, W, seed=W),
+            "blocky": lambda: blocky_pair(H, W, seed=D), "natural": lambda: natural_pair(H, W, 8, seed=H + W, sigma=8.0),
+            "flat": lambda: (np.zeros((H, W), np.float32), np.zeros((H, W), np.float32))}[mk]()
+
+
+SHAPES = [(90, 300, 9), (41, 519, 6), (27, 253, 5), (83, 64, 12), (37, 449, 4), (140, 130, 3), (5, 7, 3), (16, 128, 8), (17, 129, 9)]
+
+
+@pytest.mark.parametrize("H,W,D", SHAPES)
+@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 5, 0.13), ("random", 5, 0.5), ("blocky", 5, 0.2), ("natural", 5, 0.13),
+                                        ("natural", 3, 0.03), ("blocky", 2, 0.3), ("smooth", 0, 0.0), ("flat", 5, 1.0)])
+def test_tile_kernel_short_arms(mc, oracle, H, W, D, mk, L1, tau1):
+    x0, x1 = pair(mk, H, W, D)
+    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
+    vl, vr = raw_volumes(D, H, W, seed=13)
+    for direction, vol in ((-1, vl), (1, vr)):
+        want = oracle.cbca(x0c, x1c, vol, direction)
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, nt=(H + W) & 1, form=4)
+        got = out.cpu().numpy()
+        assert same_bits(got, want), diff_report(got, want, "tile kernel (arms <= 4) dir=%d" % direction)
+
+
+@pytest.mark.parametrize("H,W,D", SHAPES)
+@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.02), ("natural", 14, 0.02), ("blocky", 14, 0.2), ("natural", 9, 0.05),
+                                        ("blocky", 6, 0.3), ("natural", 5, 0.13), ("random", 14, 2.5), ("flat", 14, 1.0),
+                                        ("flat", 11, 1.0)])
+def test_tile_kernel_long_arms(mc, oracle, H, W, D, mk, L1, tau1):
+    x0, x1 = pair(mk, H, W, D)
+    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
+    vl, vr = raw_volumes(D, H, W, seed=13)
+    for direction, vol in ((-1, vl), (1, vr)):
+        want = oracle.cbca(x0c, x1c, vol, direction)
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, nt=(H + W) & 1, form=5)
+        got = out.cpu().numpy()
+        assert same_bits(got, want), diff_report(got, want, "tile kernel (arms <= 13) dir=%d" % direction)
+
+
+@pytest.mark.parametrize("form,L1", [(4, 5), (5, 14)])
+def test_tile_kernel_plane_range(mc, oracle, form, L1):
+    H, W, D = 30, 200, 21
+    x0, x1 = blocky_pair(H, W, seed=4)
+    x0c, x1c = oracle.cross(x0, L1, 0.2), oracle.cross(x1, L1, 0.2)
+    vl, _ = raw_volumes(D, H, W, seed=2)
+    want = oracle.cbca(x0c, x1c, vl, -1)
+    out = torch.full((1, D, H, W), -7.0, device="cuda")
+    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, d0=3, nd=13, form=form)
+    got = out.cpu().numpy()[0]
+    assert same_bits(got[3:16], want[3:16]), diff_report(got[3:16], want[3:16], "planes 3..15")
+    assert (got[:3] == -7.0).all() and (got[16:] == -7.0).all(), "planes outside [d0, d0+nd) were written"
+
+
+@pytest.mark.parametrize("form,L1", [(4, 5), (5, 14)])
+def test_tile_kernel_special_values(mc, oracle, form, L1):
+    """zeros, negative zeros, denormals, huge values, infinities and NaNs inside the valid region: a value that is not in a
+    support is never an operand of its chain -- neither a neighbour's tap nor what an accumulator collected before its
+    output's first row -- and a support of nothing but -0.0 sums to +0.0 (adcensus.cu:356)"""
+    H, W, D = 40, 260, 6
+    x0, x1 = blocky_pair(H, W, seed=8)
+    x0c, x1c = oracle.cross(x0, L1, 0.2), oracle.cross(x1, L1, 0.2)
+    vl, _ = raw_volumes(D, H, W, seed=3)
+    rng = np.random.default_rng(1)
+    vl[0, :, 20:] = 0.0
+    vl[1, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-42)
+    vl[2, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-30)
+    vl[3, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(3e38)
+    for k in range(40):
+        vl[4, rng.integers(0, H), rng.integers(20, W)] = np.inf if k & 1 else np.nan
+    vl[5, :, 20:] = -rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-38)
+    vl[5, 25:, 20:] = -0.0
+    with np.errstate(all="ignore"):
+        want = oracle.cbca(x0c, x1c, vl, -1)
+    for nt in (0, 1):
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, nt=nt, form=form)
+        got = out.cpu().numpy()
+        assert same_bits(got, want), diff_report(got, want, "tile kernel form %d, special values nt=%d" % (form, nt))
+
+
+def test_tile_kernel_stands_down_when_an_arm_is_too_long(mc, oracle):
+    """the hook's forms 4 / 5 write nothing if cbca_pack saw an arm beyond the instance's class"""
+    H, W, D = 40, 100, 3
+    x0 = np.zeros((H, W), np.float32)
+    x0c = oracle.cross(x0, 20, 1.0)
+    vl, _ = raw_volumes(D, H, W, seed=3)
+    for form in (4, 5):
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x0c), dev(vl), out, -1, form=form)
+        assert (out.cpu().numpy() == -7.0).all()
