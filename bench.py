@@ -50,7 +50,7 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 KERNEL_NAMES = {
     "join": "join_owner_kernel (StereoJoin on v_mfma_f32_32x32x2_f32, both volumes, NaN fill + fix_border folded in)",
-    "cbca": "cbca_window_kernel for L1 <= 5, cbca_strip_kernel otherwise (one launch per iteration and volume)",
+    "cbca": "cbca_tile_kernel on real-scene arm statistics, cbca_strip_kernel on textures / arms > 13 (the pair's route word picks on the device; one iteration over one volume per launch)",
     "sgm": "sgm_pass_kernel (right+left sweep, down sweep, up sweep: 3 launches over both volumes)",
 }
 
@@ -231,7 +231,9 @@ def copy_rate(device, nbytes):
     return _COPY_RATE[key]
 
 
-FP32_ADD_PEAK = 256 * 64 * 2.4e9   # scalar v_add_f32: 256 CUs x 64 lanes per cycle (4 SIMDs x 16) x 2.4 GHz = 39.3 T additions/s
+# scalar v_add_f32: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T additions/s (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles);
+# scripts/microbench/valu_rate.hip measures 55.8 T/s at 8 waves per SIMD and 36 T/s at 2 (profiles/r03_valu_rate.txt)
+FP32_ADD_PEAK = 256 * 128 * 2.4e9
 
 
 def arm_lengths(ends):
@@ -294,8 +296,8 @@ def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None, xb=
     achieved = ab[dom] / (acc[dom] * 1e-3) / 1e9
     kname = KERNEL_NAMES[dom]
     if dom == "cbca":
-        kname = ("cbca_window_kernel" if prm["L1"] <= 5 else "cbca_strip_kernel + cbca_list_kernel (+ once-per-pair classification)") + \
-                " (one iteration over one volume per launch)"
+        kname = "cbca_tile_kernel<4, ...>" if prm["L1"] <= 5 else "cbca_tile_kernel<13, ...> (real-scene arm statistics) or cbca_strip_kernel (texture), by the pair's route word"
+        kname += " (one iteration over one volume per launch)"
     rec = dict(bound="hbm", kernel=kname, picked_by="largest measured stage time", achieved=round(achieved, 1),
                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic_all.get(dom),
                launches_per_step=nl[dom], algorithmic_bytes_per_launch=round(ab[dom] / nl[dom]),
@@ -307,7 +309,7 @@ def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None, xb=
             adds = apv * 2.0 * D * H * W * (prm["cbca_i1"] + prm["cbca_i2"])   # both volumes, all iterations (NaN-triangle voxels are copies: slight overcount)
             kernels["cbca"].update(additions_per_voxel=round(apv, 2), additions_T_per_s=round(adds / (acc["cbca"] * 1e-3) / 1e12, 3),
                                    frac_of_fp32_add_peak=round(adds / (acc["cbca"] * 1e-3) / FP32_ADD_PEAK, 4),
-                                   additions_note="mean support size of the left volume at 8 disparities; peak = 39.3 T scalar fp32 additions/s")
+                                   additions_note="mean support size of the left volume at 8 disparities; peak = 78.6 T scalar fp32 additions/s (55.8 T/s measured on a pure chain of v_add_f32)")
         except Exception as e:  # never lose the bench line over a side figure
             kernels["cbca"]["additions_error"] = str(e)[:200]
     if device is not None:  # the same figures against what a plain copy of one volume reaches on THIS box
@@ -392,7 +394,22 @@ def north_star_realistic(device):
     except Exception:  # a side figure must not cost the record
         apv = float("nan")
     adds = apv * 2.0 * D * H * W * n_it
+    ops_ms = None
+    try:   # the unchanged-main.lua route (op-by-op adcensus.* calls) on the same pair: adcensus.cbca picks the same kernel on the device
+        mc.stereo_predict(xb, prm, D, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mc.stereo_predict(xb, prm, D, **kw)
+        torch.cuda.synchronize()
+        ops_ms = round((time.perf_counter() - t0) * 1e3, 2)
+    except Exception as e:
+        ops_ms = "error: %s" % str(e)[:200]
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_mb_slow_natural.json")
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get("cbca")
     rec = dict(pair=PAIR_NOTE["natural"], ms_per_pair=round(sum(acc.values()), 2), stage_ms={k: round(v, 3) for k, v in acc.items()},
+               ops_ms_per_pair=ops_ms, cbca_traffic=traffic,
                cbca_ms_per_launch=round(acc.get("cbca", 0) / (2 * n_it), 3), cbca_additions_per_voxel=round(apv, 2),
                cbca_additions_T_per_s=round(adds / (acc["cbca"] * 1e-3) / 1e12, 3),
                cbca_frac_of_fp32_add_peak=round(adds / (acc["cbca"] * 1e-3) / FP32_ADD_PEAK, 4),

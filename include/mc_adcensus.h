@@ -37,7 +37,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define MC_ABI_VERSION 4
+#define MC_ABI_VERSION 5
 #define MC_EINVAL (-22)
 #define MC_SGM_MAX_D 512   /* reference: __shared__ float[400], adcensus.cu:574 */
 #define MC_JOIN_MAX_C 128  /* reference: float L_cache[128], adcensus.cu:1460-1461 */
@@ -106,16 +106,17 @@ int mc_cross(const float *img, float *arms, int H, int W, int L1, float tau1, vo
 int mc_cbca(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
             int D, int H, int W, int direction, void *stream);
 
-/* The same operator on the fast path: the per-arm minimum lengths of the two images are packed into `scratch`
- * (mc_cbca_scratch_bytes, 4 bytes per pixel and image) and one wave walks a strip of 256 staged columns of one
- * disparity plane top to bottom (rows in registers / wave-private LDS rings, no block barrier); same accumulation
- * order, bit-identical to mc_cbca.  Two kernels are launched and the packing pass lets exactly one run: no arm longer
- * than 4 (arms from mc_cross with L1 <= 5) -> the window kernel, every lane walks the supports of its four outputs out
- * of 9-row rings (real scenes: most supports are larger than 3x3); otherwise the strip kernel, minimal 3x3 supports
- * out of registers, the others compacted per row (from the rings where they fit, from global memory otherwise).  An arm
- * longer than 254 pixels (not representable in the packed form) makes the call fall back to mc_cbca's kernel inside
- * the same call.  (mc_predict knows L1 and launches one kernel; for L1 > 5 it also classifies the pair's supports
- * once into a list sorted by size, which a third kernel walks -- see mc_cbca_ws_cfg, form 3.) */
+/* The same operator on the fast paths: the arm lengths of both images are packed into `scratch` (mc_cbca_scratch_bytes,
+ * 4 bytes per pixel and image) together with what they look like -- an arm longer than 4 / 13 / 254 pixels present, the
+ * share of pixels whose four arms are all minimal -- and a route word derived from that on the device.  Four kernels are
+ * launched and exactly one runs (the others leave at their first instruction; the host reads nothing back):
+ *   every arm <= 4 (arms from mc_cross with L1 <= 5) or <= 13 (L1 <= 14), real-scene statistics: the tile kernel
+ *     (cbca_tile.hip) -- a block streams a strip of one disparity plane through an LDS ring, a lane owns a column x 4
+ *     output rows and adds every run value once into four accumulators, items sorted by height per step;
+ *   longer arms, or a pair on which nearly every support is the minimal 3x3 (textures: a bandwidth problem): the strip
+ *     kernel -- one wave walks 256 staged columns of a plane top to bottom, minimal supports out of registers;
+ *   an arm longer than 254 pixels (not representable in the packed form): mc_cbca's kernel.
+ * Same accumulation order everywhere, bit-identical to mc_cbca.  (mc_predict knows L1 and launches fewer of them.) */
 size_t mc_cbca_scratch_bytes(int H, int W);
 int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
                int D, int H, int W, int direction, void *scratch, size_t scratch_bytes, void *stream);
@@ -263,14 +264,11 @@ int mc_predict_timed(const mc_params *p, const float *x0, const float *x1,
 
 /* ---- test / bench hooks (not part of the reference's surface) ---------------- */
 
-/* mc_cbca_ws with the launch configuration forced instead of derived from the problem: rows per strip `rb` (0 = auto),
- * cache policy `nt` (-1 = auto, 0 = default policy, 1 = non-temporal volume accesses), planes [d0, d0+nd) only
- * (nd = 0: all), kernel `form`: 0 = the one mc_cbca_ws takes, 1 = strip kernel, 2 = window kernel (what mc_predict
- * takes for L1 <= 5; requires every arm <= 4, i.e. arms from mc_cross with L1 <= 5), 3 = strip kernel + list kernel
- * (what mc_predict takes for L1 > 5: the supports that do not fit the strip kernel's window form are classified by size
- * into a list behind the packed lengths -- scratch must hold mc_cbca_scratch_bytes + mc_cbca_list_bytes -- and walked a
- * lane per entry).  Lets small-shape parity tests reach what the benchmarked sizes and parameter sets select. */
-size_t mc_cbca_list_bytes(int D, int H, int W);
+/* mc_cbca_ws with the launch configuration forced instead of derived from the problem: cache policy `nt` (-1 = auto,
+ * 0 = default policy, 1 = non-temporal volume accesses), planes [d0, d0+nd) only (nd = 0: all), kernel `form`:
+ * 0 = what mc_cbca_ws does, 1 = strip kernel (`rb` = output rows per strip, 0 = auto), 2 / 3 = tile kernel, short-arm /
+ * long-arm instance (`rb` = tile geometry variant, 0 = the product's; the launch writes NOTHING if an arm exceeds 4 / 13).
+ * Lets small-shape parity tests reach what the benchmarked sizes and parameter sets select. */
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
                    int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
                    int rb, int nt, int d0, int nd, int form, void *stream);

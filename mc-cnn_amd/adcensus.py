@@ -101,12 +101,13 @@ def cbca(x0c, x1c, vol_in, vol_out, direction):
 
 
 def cbca_cfg(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, d0=0, nd=0, form=0):
-    """Test / bench hook (mc_cbca_ws_cfg): adcensus.cbca with the launch configuration forced -- rows per strip,
-    non-temporal instantiation, plane range, kernel form (1 strip kernel, 2 window kernel: arms <= 4 only, 3 strip kernel +
-    the pair's list of large supports) -- instead of derived from the problem."""
+    """Test / bench hook (mc_cbca_ws_cfg): adcensus.cbca with the launch configuration forced -- non-temporal
+    instantiation, plane range, kernel form (0 what adcensus.cbca does, 1 strip kernel with rb rows per strip, 2 / 3 tile
+    kernel short-arm / long-arm instance with rb = geometry variant; these write nothing if an arm exceeds 4 / 13) --
+    instead of derived from the problem."""
     _chk(x0c, x1c, vol_in, vol_out)
     D, H, W = vol_out.shape[-3:]
-    need = lib.mc_cbca_scratch_bytes(H, W) + (lib.mc_cbca_list_bytes(D, H, W) if form == 3 else 0)
+    need = lib.mc_cbca_scratch_bytes(H, W)
     scratch = _scratch_for(vol_out.device, need)
     check(lib.mc_cbca_ws_cfg(_p(x0c), _p(x1c), _p(vol_in), _p(vol_out), D, H, W, int(direction), scratch.data_ptr(), need,
                              int(rb), int(nt), int(d0), int(nd), int(form), _stream()), "cbca_cfg")

@@ -1,6 +1,6 @@
 // extern "C" surface of libmcadcensus.so (see include/mc_adcensus.h) and the fused
 // stereo_predict pipeline (main.lua:929-1082).
-#include "mc_common.h"
+#include "cbca_common.h"
 
 #include <stdarg.h>
 #include <algorithm>
@@ -37,12 +37,10 @@ size_t cbca_scratch_bytes(int H, int W);
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st);
 int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
                      int direction, hipStream_t st);
-int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm,
-               hipStream_t st, const CbcaCfg &cfg = CbcaCfg(), const void *listmem = nullptr);
-int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int gate,
+int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int route,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
-size_t cbca_list_bytes(int D, int H, int W);
-int cbca_list_build(const void *packed, void *listmem, int D, int H, int W, int direction, hipStream_t st);
+int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int route,
+               hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
 size_t conv3x3_workspace_bytes(int Cin, int Cout);
 int conv3x3(const float *in, const float *w, const float *bias, float *out, int N, int Cin, int Cout, int H, int W, int relu,
             void *workspace, hipStream_t st);
@@ -116,16 +114,27 @@ static int gaussian_cached(double sigma, GaussianK &out)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// cbca by lists: arms longer than the window kernel's (L1 > 5), short enough for the packed lengths, 32-bit voxel indices
-static bool cbca_listed_mode(int L1, int D, int H, int W)
+// One aggregation pass over packed arm lengths (cbca_pack).  max_arm = the largest arm that can occur (L1 - 1 where L1 is
+// known, < 0 where it is not: adcensus.cbca).  Arms <= 4: the tile kernel's short-arm instance.  Otherwise the pair's
+// route word (cbca_pack: arm classes actually present, share of pixels with unit arms) decides on the device between the
+// tile kernel's two instances and the strip kernel -- the launches that are not the pair's stand down at their first
+// instruction; nothing is read back by the host.
+static int cbca_by_arms(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm, hipStream_t st,
+                        const CbcaCfg &cfg = CbcaCfg())
 {
-	return L1 - 1 > 4 && L1 - 1 <= 254 && (int64_t)D * H * W < ((int64_t)1 << 31) && (int64_t)H * W < ((int64_t)1 << 29) - 4096;
+	if (max_arm >= 0 && max_arm <= 4) return cbca_tiles(packed, vin, vout, D, H, W, direction, 4, -1, st, cfg);
+	int rc = cbca_tiles(packed, vin, vout, D, H, W, direction, 4, CR_TILE4, st, cfg);
+	if (rc) return rc;
+	if (max_arm < 0 || max_arm <= 13) {
+		rc = cbca_tiles(packed, vin, vout, D, H, W, direction, 13, CR_TILE13, st, cfg);
+		if (rc) return rc;
+	}
+	return cbca_strips(packed, vin, vout, D, H, W, direction, max_arm > 13 ? CR_STRIP_OR_TILE13 : CR_STRIP, st, cfg);
 }
 
 struct Plan {
 	int Dp;                 // padded pixel stride of the (H,W,Dp) volumes
 	size_t maps, arms, pack, vol, img, gk;
-	size_t list;            // per direction: the outputs cbca_list_kernel owns (L1 > 5 only, else 0)
 	size_t total;
 };
 
@@ -142,10 +151,7 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	const int kr = (int)ceil(p->blur_sigma * 3);
 	const int ks = 2 * kr + 1;
 	pl.gk = align_up((size_t)ks * ks * sizeof(float), 256);
-	// long arms (L1 > 5): the supports that do not fit the strip kernel's window form are listed once per pair and direction
-	const bool uses_cbca = p->cbca_i1 + p->cbca_i2 > 0;
-	pl.list = (uses_cbca && cbca_listed_mode(p->L1, D, H, W)) ? cbca_list_bytes(D, H, W) : 0;
-	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk + 2 * pl.list;
+	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk;
 	return pl;
 }
 
@@ -217,10 +223,6 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	bufC[1] = (float *)w; w += pl.vol;
 	float *img[6];
 	for (int i = 0; i < 6; ++i) { img[i] = (float *)w; w += pl.img; }
-	void *lists[2] = {nullptr, nullptr};
-	if (pl.list) {
-		lists[0] = w + pl.gk; lists[1] = w + pl.gk + pl.list;   // behind the Gaussian kernel, which follows the images
-	}
 	float *gk = (float *)w;
 	const int Dp = pl.Dp;
 	int rc;
@@ -261,21 +263,13 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	// (mb_directions, main.lua:953-955) -- only when nothing of it is asked for
 	const int nvol = (p->left_only && !p->lr_check && !volR_out && !dispR0_out) ? 1 : 2;
 	// n CBCA iterations on the (D,H,W) volumes, ping-pong between the two buffers of each side (instead of vol:copy(tmp))
-	bool lists_built = false;
 	auto cbca_iterations = [&](int n) -> int {
-		const bool strips = cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096;  // packed lengths saturate at 255
-		if (n > 0 && pl.list && !lists_built) {  // long arms: classify the pair's supports once, for both aggregation blocks
-			for (int v = 0; v < nvol; ++v) {
-				const int rc2 = cbca_list_build(packed, lists[v], D, H, W, direction[v], st);
-				if (rc2) return rc2;
-			}
-			lists_built = true;
-		}
+		const bool packed_ok = cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096;  // packed lengths saturate at 255
 		for (int i = 0; i < n; ++i) {
 			for (int v = 0; v < nvol; ++v) {
 				float *dst = other(v);
-				const int rc2 = strips ? cbca_strips(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st, CbcaCfg(), pl.list ? lists[v] : nullptr)
-				                       : cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st);
+				const int rc2 = packed_ok ? cbca_by_arms(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st)
+				                          : cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st);
 				if (rc2) return rc2;
 				cur[v] = dst;
 			}
@@ -565,12 +559,10 @@ int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *v
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
-	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st);
+	rc = cbca_by_arms(scratch, vol_in, vol_out, D, H, W, direction, -1, st);
 	if (rc) return rc;
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
 }
-
-size_t mc_cbca_list_bytes(int D, int H, int W) { return cbca_list_bytes(D, H, W); }
 
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
                    void *scratch, size_t scratch_bytes, int rb, int nt, int d0, int nd, int form, void *stream)
@@ -583,27 +575,20 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
 	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws_cfg: image too large for 32-bit plane offsets");
-	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 5, "mc_cbca_ws_cfg: bad rb / nt / form");
+	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 3, "mc_cbca_ws_cfg: bad rb / nt / form");
 	MC_REQUIRE(d0 >= 0 && nd >= 0 && d0 + nd <= D, "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
 	CbcaCfg cfg;
-	cfg.rb = rb; cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd; cfg.form = form == 3 ? 1 : form;
-	if (form >= 4)   // tile kernel, short-arm (4) / long-arm (5) instance; stands down (nothing written) if an arm exceeds 4 / 13
-		return cbca_tiles(scratch, vol_in, vol_out, D, H, W, direction, form == 4 ? 4 : 13, form == 4 ? 1 : 4, st, cfg);
-	const void *listmem = nullptr;
-	if (form == 3) {  // strip kernel + list kernel (what mc_predict runs for L1 > 5): the list lives behind the packed lengths
-		MC_REQUIRE(d0 == 0 && nd == 0, "mc_cbca_ws_cfg: form 3 processes whole volumes");
-		MC_REQUIRE((int64_t)D * H * W < ((int64_t)1 << 31), "mc_cbca_ws_cfg: form 3 needs D*H*W < 2^31");
-		MC_REQUIRE(scratch_bytes >= cbca_scratch_bytes(H, W) + cbca_list_bytes(D, H, W), "mc_cbca_ws_cfg: form 3 needs %zu bytes of scratch",
-		           cbca_scratch_bytes(H, W) + cbca_list_bytes(D, H, W));
-		void *lm = (char *)scratch + cbca_scratch_bytes(H, W);
-		rc = cbca_list_build(scratch, lm, D, H, W, direction, st);
-		if (rc) return rc;
-		listmem = lm;
+	cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd;
+	if (form >= 2) {   // tile kernel, short-arm (2) / long-arm (3) instance, rb = geometry variant; nothing is written if an arm exceeds 4 / 13
+		cfg.variant = rb;
+		return cbca_tiles(scratch, vol_in, vol_out, D, H, W, direction, form == 2 ? 4 : 13, form == 2 ? CR_ARMS_LE4 : CR_ARMS_LE13, st, cfg);
 	}
-	rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg, listmem);
+	cfg.rb = rb;
+	rc = form == 1 ? cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT, st, cfg)
+	               : cbca_by_arms(scratch, vol_in, vol_out, D, H, W, direction, -1, st, cfg);
 	if (rc) return rc;
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
 }

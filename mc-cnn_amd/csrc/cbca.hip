@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) cbca_direct_kernel(const float *__restric
                                                           const float *__restrict__ vol, float *__restrict__ out, int D, int H, int W,
                                                           int direction, const uint32_t *__restrict__ only_if)
 {
-	if (only_if && !*only_if) return;  // standalone fast path handled this call (no arm saturated the packed form)
+	if (only_if && only_if[CF_ROUTE] != CR_DIRECT) return;  // (the packed forms handle this pair)
 	const int x = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
 	const int d = blockIdx.z;
@@ -97,21 +97,37 @@ int cbca(const float *x0c, const float *x1c, const float *vin, float *vout, int 
 // packed once per pair as 4 bytes per pixel (L,R,U,D; saturated at 255) by cbca_pack_kernel.
 
 __global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict__ arms, uint32_t *__restrict__ packed, int H, int W,
-                                                        uint32_t *__restrict__ overflow)
+                                                        uint32_t *__restrict__ flags, int image)
 {
 	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t HW = (int64_t)H * W;
-	if (id >= HW) return;
-	const int x = (int)(id % W), y = (int)(id / W);
-	const int l = x - (int)arms[0 * HW + id] - 1;
-	const int r = (int)arms[1 * HW + id] - x - 1;
-	const int u = y - (int)arms[2 * HW + id] - 1;
-	const int d = (int)arms[3 * HW + id] - y - 1;
-	auto sat = [](int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
-	packed[id] = sat(l) | (sat(r) << 8) | (sat(u) << 16) | (sat(d) << 24);
-	if (overflow && (l > 254 || r > 254 || u > 254 || d > 254)) atomicOr(overflow, 1u);
-	if (overflow && (l > 4 || r > 4 || u > 4 || d > 4)) atomicOr(overflow + 1, 1u);   // an arm beyond the short-arm kernels (L1 <= 5)
-	if (overflow && (l > 13 || r > 13 || u > 13 || d > 13)) atomicOr(overflow + 2, 1u);   // an arm beyond the tile kernel's long-arm instance (L1 <= 14)
+	bool unit = false;
+	if (id < HW) {
+		const int x = (int)(id % W), y = (int)(id / W);
+		const int l = x - (int)arms[0 * HW + id] - 1;
+		const int r = (int)arms[1 * HW + id] - x - 1;
+		const int u = y - (int)arms[2 * HW + id] - 1;
+		const int d = (int)arms[3 * HW + id] - y - 1;
+		auto sat = [](int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+		packed[id] = sat(l) | (sat(r) << 8) | (sat(u) << 16) | (sat(d) << 24);
+		if (l > 254 || r > 254 || u > 254 || d > 254) atomicOr(flags + CF_SATURATED, 1u);
+		if (l > 4 || r > 4 || u > 4 || d > 4) atomicOr(flags + CF_ARM_GT4, 1u);      // an arm beyond the tile kernel's short-arm instance (L1 <= 5)
+		if (l > 13 || r > 13 || u > 13 || d > 13) atomicOr(flags + CF_ARM_GT13, 1u);  // ... beyond its long-arm instance (L1 <= 14)
+		unit = l <= 1 && r <= 1 && u <= 1 && d <= 1;
+	}
+	// pixels whose four arms are all at the minimum: where nearly every pixel of both images is one, nearly every support
+	// is the minimal 3 x 3 and aggregation is a bandwidth problem (the strip kernel's regime)
+	const unsigned long long m = __ballot(unit);
+	if ((threadIdx.x & 63) == 0 && m) atomicAdd(flags + CF_UNIT_PIXELS + image, (uint32_t)__builtin_popcountll(m));
+}
+
+// the kernel the pair's arms call for (one thread, after both cbca_pack_kernel launches)
+__global__ void cbca_route_kernel(uint32_t *__restrict__ flags, int64_t HW)
+{
+	// measured (1000x1500x256, L1 = 14): Gaussian texture -- 87 / 93 % of the two images' pixels have unit arms -- strip kernel 0.97 ms
+	// per launch against the tile kernel's 1.75; real-scene statistics -- 28 / 30 % -- 56 ms against 3.8.  Threshold: 75 % on average.
+	const bool textured = ((int64_t)flags[CF_UNIT_PIXELS] + (int64_t)flags[CF_UNIT_PIXELS + 1]) * 2 >= HW * 3;
+	flags[CF_ROUTE] = flags[CF_SATURATED] ? CR_DIRECT : (!flags[CF_ARM_GT4] ? CR_TILE4 : ((flags[CF_ARM_GT13] || textured) ? CR_STRIP : CR_TILE13));
 }
 
 // =====================================================================================================
@@ -129,14 +145,12 @@ __global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict_
 // re-runs the reference's loop (rows ascending, x ascending, one accumulator) for list entry i -- out of the ring where
 // the support lies inside rows y-2..y+1 / the strip's 256 columns and out of global memory otherwise -- and patches
 // the row of results in LDS before it is stored.
-// This is the kernel for images on which nearly every support is the minimal 3x3 (Gaussian textures: bandwidth-bound).
-// On real scenes most supports are larger and a pass runs at the pace of its largest one: there the window kernel
-// (arms <= 4) or, for longer arms, the LISTED instantiation takes over -- the supports that do not fit the window form by
-// their SHAPE are then skipped here (the value stored for them is provisional) and come from the pair's list
-// (cbca_list_kernel, launched after this kernel on the same stream).
+// This is the kernel for images on which nearly every support is the minimal 3x3 (Gaussian textures: bandwidth-bound),
+// and for arms beyond the tile kernel's (L1 > 14).  On real scenes most supports are larger and a pass runs at the pace of
+// its largest one: there the tile kernel (cbca_tile.hip) takes over.
 // CS_RING rows per ring, CS_LA rows committed below the current output row (two rows are staged above the first output
 // row of a chunk: the window form reaches two rows up), CS_WR column radius of the window form
-template <int PF, int CS_RING, int CS_LA, int CS_WR, bool NT, bool LISTED>
+template <int PF, int CS_RING, int CS_LA, int CS_WR, bool NT>
 __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 {
 	constexpr int CS_UP = 2;   // rows staged above the first output row: the window form reaches two rows up
@@ -149,7 +163,7 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 	__shared__ cb_u32 Mring[4][CS_RING * CS_COLS];
 	__shared__ float Rrow[4][CS_COLS];          // results of the current row (patched by the compacted pass)
 	__shared__ cb_u32 Clist[4][CS_COLS];        // outputs that need the general loop: frame column | up << 16 | down << 24
-	if (A.overflow && (A.overflow[0] || (A.by_arm && !A.overflow[1]))) return;   // (by_arm: the pair has short arms only, the window kernel runs)
+	if (!cbca_gate(A.flags, A.route)) return;   // (the pair's arms call for another kernel)
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane descriptors stay in SGPRs
 	float *__restrict__ V = Vring[wv];
@@ -326,7 +340,6 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 						for (int t = 0; t < 2 * CS_WR + 1; ++t) tv[k][t] = V[ro_ + t - CS_WR];
 					}
 					bool ok = u <= 2 && dn <= CS_LA && yo - u >= lo_row && yo + dn <= hi_row;
-					bool fits = u <= 2 && dn <= CS_LA;   // the support's shape alone (cbca_fits_window): inside rows -2 .. +LA, columns +-WR
 					float sum = 0;
 					int cnt = 0;
 #pragma unroll
@@ -335,7 +348,6 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 						const bool act = rel >= -u && rel <= dn;
 						const int l = (int)(mm[k] & 0xff), rg = (int)((mm[k] >> 8) & 0xff);
 						ok = ok && (!act || (l <= CS_WR && rg <= CS_WR && c - l >= 0 && c + rg < CS_COLS));
-						fits = fits && (!act || (l <= CS_WR && rg <= CS_WR));
 						const int la = act ? l : -1, rga = act ? rg : -1;   // inactive row: no tap passes
 #pragma unroll
 						for (int t = 0; t < 2 * CS_WR + 1; ++t) {
@@ -345,10 +357,8 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 						}
 						cnt += act ? l + rg + 1 : 0;
 					}
-					// LISTED: a support that does not fit the window by its shape is in the pair's list and is left to
-					// cbca_list_kernel, which runs after this launch (the value stored here is provisional)
 					if (ok) R[c] = sum / (float)cnt;
-					else if (!LISTED || fits) R[c] = general(yo, c, u, dn, lo_row, hi_row);
+					else R[c] = general(yo, c, u, dn, lo_row, hi_row);
 				}
 			}
 			const cb_f2 r0 = *(const cb_f2 *)(R + c0 + 2), r1 = *(const cb_f2 *)(R + c1 + (lane < 63 ? 0 : 2));
@@ -381,561 +391,6 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 }
 
 
-// =====================================================================================================
-// cbca: window form for short arms (L1 <= 5) -- every lane walks its own supports
-// =====================================================================================================
-// Real 8-bit scenes are the opposite regime of the strip kernel's.  Under the KITTI thresholds (L1 = 5, tau1 = 0.13) 90 %
-// of the outputs have a support larger than the minimal 3x3 and almost half of the arms sit at the L1-1 = 4 limit
-// (measured on the reference's sample pair; tests/util.natural_pair reproduces the statistics): about 40 additions per
-// voxel in a fixed order, compute-bound.  The strip kernel's compaction list then holds every output of the row and its
-// general loop runs at the pace of the largest support of each pass, from global memory: 6.2 ms per launch at
-// 370x1226x228 against 0.8 ms on a Gaussian texture.
-//
-// Here a wave owns a plane, a strip of 256 staged columns (248 outputs, +-4 halo) and RB rows; rings of 9 rows (values,
-// run masks of the minimum arm lengths) cover every support of the output row 4 rows behind the newest one.  A lane owns four
-// adjacent outputs.  Per support row it reads its 12-column window once (3 x ds_read_b128) and, per output, turns the
-// row's (left, right) into a 9-bit run mask; each of the 9 taps is then  sum += bit ? value : -0.0f  as v_bfe_i32 +
-// v_bfi_b32 + v_add_f32.  x + (-0.0f) == x exactly and a value that is not selected is never an operand, so the chain of
-// additions is the reference's (rows ascending, x ascending, one accumulator from +0.0) whatever the unselected columns
-// hold (NaN triangle included).  The row loop runs over the wave's largest up / down arm and the 5-tap form is used on
-// rows where no lane reaches beyond +-2, so textured areas cost a 3 x 5 window.
-// (A version of this kernel for arms up to 13 -- 27-row rings, a second walk over +-13 rows -- is in the history, commit
-// c898b0c: bit-exact, but slower than one thread per voxel on the realistic pair)
-constexpr int CW_ARM = 4;                    // largest arm the window covers
-constexpr int CW_STEP = CS_COLS - 2 * CW_ARM;   // 248 output columns per strip (frame columns 4 .. 251)
-constexpr int CW_RING = 2 * CW_ARM + 1;
-constexpr int CW_VPITCH = CS_COLS + 8;       // 4 columns of padding on either side: the outermost lanes' windows stay inside the row
-constexpr int CW_WAVES = 2;                  // waves per block (each has its own rings)
-
-template <bool NT>
-__global__ void __launch_bounds__(64 * CW_WAVES) cbca_window_kernel(const CbcaArgs A)
-{
-	constexpr int VOL_AUX = NT ? 2 : 0;
-	__shared__ __attribute__((aligned(16))) float Vring[CW_WAVES][CW_RING][CW_VPITCH];
-	__shared__ __attribute__((aligned(16))) unsigned short Mring[CW_WAVES][CW_RING][CS_COLS];
-	if (A.overflow && (A.overflow[0] || (A.by_arm && A.overflow[1]))) return;   // (by_arm: the pair has an arm > 4, the strip kernel runs)
-	const int lane = threadIdx.x & 63;
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int H = A.H, W = A.W, direction = A.direction;
-	const int HWi = H * W;
-	// wave -> (region, d) as in the strip kernel: the waves of a block take consecutive disparities of one region, the
-	// blocks of an XCD walk all disparity groups of a region before the next one
-	const int dgroups = (A.nd + CW_WAVES - 1) / CW_WAVES;
-	const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
-	const int region = (kb / dgroups) * 8 + xcd;
-	const int d = A.d0 + (kb % dgroups) * CW_WAVES + wv;
-	if (region >= A.gx * A.gy || d >= A.d0 + A.nd) return;
-	const int cx = region % A.gx, cy = region / A.gx;
-	const int sh = d * direction;
-	const int xs0 = cx * CW_STEP - CW_ARM;        // image column of frame column 0 (wave-uniform)
-	const int xs = xs0 + 4 * lane;                // image column of this lane's four columns = its four outputs
-	const int y0 = cy * A.rb, y1 = min(H, y0 + A.rb);
-	const int ra = y0 - CW_ARM;                   // first staged row
-	const int plane_bytes = HWi * 4;
-	const cb_u32 OOB = 0x80000000u;
-	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
-	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
-	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
-	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
-	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
-	const bool full_in = xs >= 0 && xs + 3 < W;
-	const bool has_out = lane >= 1 && lane <= 62;
-	const bool full_out = has_out && xs + 3 < W;
-	const bool any_out = has_out && xs < W;
-	bool exists[4], inr[4];   // output column exists / its shifted partner is inside the image (adcensus.cu:353-354)
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const int x = xs + j;
-		exists[j] = has_out && x < W;
-		inr[j] = x + sh >= 0 && x + sh < W;
-	}
-	float *__restrict__ Vw = &Vring[wv][0][0];
-	unsigned short *__restrict__ Mw = &Mring[wv][0][0];
-
-	struct Stage { cb_u4 v, a, b; };
-	auto fetch = [&](Stage &st, int r) {  // values and lengths of row r -> registers (rows outside the image: zeros)
-		const bool rok = r >= 0 && r < H;
-		const int base = r * W + xs;
-		if (full_in) {
-			st.v = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)base * 4u : OOB, 0, VOL_AUX);
-		} else {
-			cb_u32 t[4];
-#pragma unroll
-			for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_raw_buffer_load_b32(rv, (rok && xs + k >= 0 && xs + k < W) ? (cb_u32)(base + k) * 4u : OOB, 0, 0);
-			st.v = cb_u4{t[0], t[1], t[2], t[3]};
-		}
-		st.a = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
-		st.b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
-	};
-	// per column 16 bits: the row's 9-bit RUN MASK (bit k <-> column offset k - 4 belongs to the run: it depends on the
-	// row's left / right lengths only, so it is built once per row here and not once per output row that uses it), up in
-	// bits 9..11, down in bits 12..14 (every arm this kernel is launched for is <= CW_ARM = 4)
-	auto nib = [](cb_u32 m) -> cb_u32 {
-		const cb_u32 l = m & 0xffu, r = (m >> 8) & 0xffu, u = (m >> 16) & 0xffu, d = m >> 24;
-		const cb_u32 run = ((1u << (l + r + 1u)) - 1u) << (CW_ARM - l);
-		return (run & 0x1ffu) | ((u & 7u) << 9) | ((d & 7u) << 12);
-	};
-	auto commit = [&](const Stage &st, int slot) {
-		*(cb_u4 *)(Vw + slot * CW_VPITCH + 4 + 4 * lane) = st.v;
-		const cb_u32 m0 = nib(bytemin4(st.a.x, st.b.x)), m1 = nib(bytemin4(st.a.y, st.b.y));
-		const cb_u32 m2 = nib(bytemin4(st.a.z, st.b.z)), m3 = nib(bytemin4(st.a.w, st.b.w));
-		*(cb_u2 *)(Mw + slot * CS_COLS + 4 * lane) = cb_u2{m0 | (m1 << 16), m2 | (m3 << 16)};
-	};
-
-	auto output = [&](int yo, int rs) {  // rs = ring slot of the newest row yo + CW_ARM
-		// own lengths: the up / down arms bound the rows, negative = this output takes no taps at all
-		int s0 = rs + (CW_RING - CW_ARM);
-		s0 = s0 >= CW_RING ? s0 - CW_RING : s0;
-		const cb_u2 mo = *(const cb_u2 *)(Mw + s0 * CS_COLS + 4 * lane);
-		const cb_u32 ud[4] = {(mo.x >> 9) & 0x3fu, mo.x >> 25, (mo.y >> 9) & 0x3fu, mo.y >> 25};   // up | down << 3
-		int up[4], dn[4], umax = 0, dmax = 0;
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const bool take = exists[j] && inr[j];
-			up[j] = take ? (int)(ud[j] & 7u) : -1;
-			dn[j] = take ? (int)((ud[j] >> 3) & 7u) : -1;
-			umax = max(umax, up[j]);
-			dmax = max(dmax, dn[j]);
-		}
-		int Uw = 0, Dw = 0;   // the wave's largest arms (0 .. 4): ballots
-#pragma unroll
-		for (int t = 1; t <= CW_ARM; ++t) {
-			Uw = __any(umax >= t) ? t : Uw;
-			Dw = __any(dmax >= t) ? t : Dw;
-		}
-		// the reference's accumulator starts at +0.0 and the first tap may be -0.0f: the zero is made opaque so that
-		// "0 + x" stays an addition
-		float sum[4], own[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-		for (int j = 0; j < 4; ++j) asm("v_mov_b32 %0, 0" : "=v"(sum[j]));
-		int cnt[4] = {0, 0, 0, 0};
-		for (int rel = -Uw; rel <= Dw; ++rel) {
-			int sl = rs - CW_ARM + rel;                       // slot of row yo + rel
-			sl = sl < 0 ? sl + CW_RING : sl;
-			const float *__restrict__ vr = Vw + sl * CW_VPITCH + 4 * lane;   // frame column 4*lane - 4
-			const cb_f4 q0 = *(const cb_f4 *)vr, q1 = *(const cb_f4 *)(vr + 4), q2 = *(const cb_f4 *)(vr + 8);
-			const float v[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-			const cb_u2 mr = *(const cb_u2 *)(Mw + sl * CS_COLS + 4 * lane);
-			const cb_u32 mrow[4] = {mr.x, mr.x >> 16, mr.y, mr.y >> 16};   // low 9 bits: the row's run mask
-			if (rel == 0) {
-#pragma unroll
-				for (int j = 0; j < 4; ++j) own[j] = v[4 + j];
-			}
-			const int arel = rel < 0 ? -rel : rel;
-			cb_u32 mask[4], anywide = 0;
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const int need = rel < 0 ? up[j] : dn[j];
-				mask[j] = need >= arel ? (mrow[j] & 0x1ffu) : 0u;
-				cnt[j] += __builtin_popcount(mask[j]);
-				anywide |= mask[j];
-			}
-			const bool wide = __any((anywide & 0x183u) != 0);   // a tap at +-3 or +-4 somewhere in the wave
-			auto taps = [&](auto first_k, auto last_k) {
-#pragma unroll
-				for (int j = 0; j < 4; ++j) {
-#pragma unroll
-					for (int k = first_k; k <= last_k; ++k) {
-						const cb_u32 keep = (cb_u32)(((int)(mask[j] << (31 - k))) >> 31);   // all ones if the tap is in the run
-						float t;   // keep ? value : -0.0f as ONE bit-field insert (left to itself the compiler shares partial
-						           // and/or terms between taps and ends up with four to five operations per tap)
-						asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(t) : "v"(keep), "v"(v[j + k]), "s"(0x80000000u));
-						sum[j] += t;
-					}
-				}
-			};
-			if (wide) taps(std::integral_constant<int, 0>(), std::integral_constant<int, 8>());
-			else taps(std::integral_constant<int, 2>(), std::integral_constant<int, 6>());
-		}
-		float res[4];
-#pragma unroll
-		for (int j = 0; j < 4; ++j) res[j] = inr[j] ? sum[j] / (float)cnt[j] : own[j];   // adcensus.cu:353-354: copied through
-		const int ob = yo * W + xs;
-		if (full_out) {
-			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
-			                                       ro, (cb_u32)ob * 4u, 0, VOL_AUX);
-		} else if (any_out) {
-#pragma unroll
-			for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[j]), ro, xs + j < W ? (cb_u32)(ob + j) * 4u : OOB, 0, 0);
-		}
-	};
-
-	constexpr int PF = 2;
-	Stage st[PF];
-#pragma unroll
-	for (int u = 0; u < PF; ++u) fetch(st[u], ra + u);
-	const int last = y1 - 1 + CW_ARM;
-	int rs = 0;   // ring slot of the row being committed
-	for (int g = ra; g <= last; g += PF) {
-#pragma unroll
-		for (int u = 0; u < PF; ++u) {
-			const int r = g + u;
-			if (r > last) break;
-			commit(st[u], rs);
-			fetch(st[u], r + PF);
-			const int yo = r - CW_ARM;
-			if (yo >= y0 && yo < y1) output(yo, rs);
-			rs = rs + 1 == CW_RING ? 0 : rs + 1;
-		}
-	}
-}
-
-// =====================================================================================================
-// cbca for long arms (L1 > 5): supports sorted by size, once per pair
-// =====================================================================================================
-// On real scenes under the Middlebury thresholds (L1 = 14, tau1 = 0.02) half of the supports are the minimal 3x3, 84 %
-// hold at most 25 taps and 4-6 % are flat regions of up to 27 x 27 = 729 taps that carry two thirds of all additions
-// (tests/util.natural_pair).  Every output is ONE serial chain of additions, so a wave runs at the pace of its largest
-// support: the strip kernel's per-row passes (56 ms per launch at 1000x1500x256) and one thread per voxel (21 ms) both
-// spend most of their lanes waiting.  The supports do not change between the 2 + 16 iterations of a pair, so they are
-// classified ONCE per pair and direction: every output whose support does not fit the strip kernel's window form by its
-// shape goes, by size class, into a list of voxel indices (count pass, prefix, fill pass).  Per iteration the strip kernel
-// (LISTED) then skips those outputs and cbca_list_kernel walks the list, a lane per entry: the lanes of a wave hold
-// supports of one size class, and a persistent grid strides over the list so that all CUs work on the same class at a time.
-constexpr int CL_BUCKETS = 8;
-constexpr int CL_BLOCKS = 2048;   // persistent grid of the classification passes (8 blocks per CU)
-struct CbcaListHdr {
-	uint32_t total;
-	uint32_t pad[31];
-	uint32_t block[CL_BLOCKS][CL_BUCKETS];   // count pass: entries of block k in class b; after the scan: its first entry
-};
-
-// A list entry: the voxel index and, where the support has at most 9 rows and arms <= 15, its shape -- w[0] bits 0..3 up,
-// 4..7 down, then one byte (left | right << 4) per support row from the top one -- so that the list kernel fetches an
-// entry with ONE coalesced 16-byte load instead of two scattered length loads per support row (it was bound by the
-// L1's line rate: 4.4 G line accesses per launch, 21 per load instruction).  w[2] bit 31: no shape, walk the packed maps.
-struct __attribute__((aligned(16))) CbcaListEntry { uint32_t id, w[3]; };
-constexpr uint32_t CL_NOSHAPE = 0x80000000u;
-
-__device__ __forceinline__ int cl_bucket(int size)
-{
-	return size <= 12 ? 0 : size <= 20 ? 1 : size <= 32 ? 2 : size <= 56 ? 3 : size <= 100 ? 4 : size <= 200 ? 5 : size <= 400 ? 6 : 7;
-}
-
-// shape test shared with the strip kernel (its `fits`): rows -2 .. +1, columns +-2 -- and the support's tap count
-__device__ __forceinline__ bool cbca_listed(const uint32_t *__restrict__ p0, const uint32_t *__restrict__ p1, int y, int x, int sh, int W,
-                                            int &size)
-{
-	const int g0 = y * W + x;
-	const uint32_t own = bytemin4(p0[g0], p1[g0 + sh]);
-	const int u = (int)((own >> 16) & 0xff), dn = (int)(own >> 24);
-	bool fits = u <= 2 && dn <= 1;
-	int n = 0;
-	for (int q = y - u; q <= y + dn; ++q) {
-		const int g = q * W + x;
-		const uint32_t mm = q == y ? own : bytemin4(p0[g], p1[g + sh]);
-		const int l = (int)(mm & 0xff), r = (int)((mm >> 8) & 0xff);
-		fits = fits && l <= 2 && r <= 2;
-		n += l + r + 1;
-	}
-	size = n;
-	return !fits;
-}
-
-// A block owns a contiguous range of (plane, 4 rows, 64 columns) tiles and keeps its eight class counters in LDS:
-// FILL = false classifies its outputs (class byte per voxel, 0xff = not listed) and counts them per class, FILL = true
-// (after the scan has turned the counts into first positions) walks the same tiles again, reads the class bytes and
-// writes the voxel indices.  No global atomics.
-template <bool FILL>
-__global__ void __launch_bounds__(256) cbca_list_build_kernel(const uint32_t *__restrict__ p0, const uint32_t *__restrict__ p1,
-                                                              CbcaListHdr *__restrict__ hdr, CbcaListEntry *__restrict__ list,
-                                                              uint8_t *__restrict__ cls, int D, int H, int W, int direction)
-{
-	__shared__ uint32_t cur[CL_BUCKETS];
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	if (threadIdx.x < CL_BUCKETS) cur[threadIdx.x] = FILL ? hdr->block[blockIdx.x][threadIdx.x] : 0u;
-	__syncthreads();
-	const int tx = (W + 63) >> 6, ty = (H + 3) >> 2;
-	const int64_t tiles = (int64_t)tx * ty * D;
-	const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
-	const int64_t t0 = per * blockIdx.x, t1 = min(tiles, t0 + per);
-	// what a tile row needs from memory is fetched one tile ahead: the loop is a chain of round trips otherwise (a block
-	// walks ~750 tiles one after the other)
-	struct Pre {
-		int x, y, sh;
-		bool inside, valid;
-		uint32_t id;
-		uint32_t a0, a1, o0, o1, b0, b1;   // count pass: lengths of rows y-1, y, y+1 in both images
-		int cls;                           // fill pass: the class byte
-	};
-	// tile coordinates advance by counters (a 64-bit division per tile was most of the kernel's instructions)
-	int fbx = (int)(t0 % tx), fby = (int)((t0 / tx) % ty), fd = (int)(t0 / ((int64_t)tx * ty));
-	auto fetch = [&](int64_t t) -> Pre {
-		Pre q;
-		const int bx = fbx, by = fby, d = fd;
-		if (++fbx == tx) {
-			fbx = 0;
-			if (++fby == ty) { fby = 0; ++fd; }
-		}
-		q.x = bx * 64 + lane; q.y = by * 4 + wv;
-		q.sh = d * direction;
-		q.inside = t < t1 && q.x < W && q.y < H;
-		q.valid = q.inside && q.x + q.sh >= 0 && q.x + q.sh < W;
-		q.id = (uint32_t)((d * H + q.y) * W + q.x);
-		q.a0 = q.a1 = q.o0 = q.o1 = q.b0 = q.b1 = 0;
-		q.cls = -1;
-		if (FILL) {
-			if (q.inside) q.cls = (int)(int8_t)cls[q.id];   // 0xff -> -1
-		} else if (q.valid) {
-			const int g = q.y * W + q.x, ga = max(q.y - 1, 0) * W + q.x, gb = min(q.y + 1, H - 1) * W + q.x;
-			q.a0 = p0[ga]; q.a1 = p1[ga + q.sh]; q.o0 = p0[g]; q.o1 = p1[g + q.sh]; q.b0 = p0[gb]; q.b1 = p1[gb + q.sh];
-		}
-		return q;
-	};
-	Pre nxt = fetch(t0);
-	for (int64_t t = t0; t < t1; ++t) {
-		const Pre c = nxt;
-		nxt = fetch(t + 1);
-		const int x = c.x, y = c.y, sh = c.sh;
-		const bool inside = c.inside;
-		const uint32_t id = c.id;
-		int bucket = -1;
-		if (FILL) {
-			bucket = c.cls;
-		} else {
-			if (c.valid) {
-				// most supports reach one row up and down: the three rows' lengths were fetched together; only taller
-				// supports walk their rows one after the other
-				const uint32_t own = bytemin4(c.o0, c.o1);
-				const int u = (int)((own >> 16) & 0xff), dn = (int)(own >> 24);
-				if (u <= 1 && dn <= 1) {
-					const uint32_t ma = bytemin4(c.a0, c.a1), mb = bytemin4(c.b0, c.b1);
-					auto lr = [](uint32_t m, int &l, int &r) { l = (int)(m & 0xff); r = (int)((m >> 8) & 0xff); };
-					int l, r, n;
-					lr(own, l, r);
-					bool fits = l <= 2 && r <= 2;
-					n = l + r + 1;
-					if (u == 1) { lr(ma, l, r); fits = fits && l <= 2 && r <= 2; n += l + r + 1; }
-					if (dn == 1) { lr(mb, l, r); fits = fits && l <= 2 && r <= 2; n += l + r + 1; }
-					if (!fits) bucket = cl_bucket(n);
-				} else {
-					int size;
-					if (cbca_listed(p0, p1, y, x, sh, W, size)) bucket = cl_bucket(size);
-				}
-			}
-			if (inside) cls[id] = (uint8_t)bucket;
-		}
-		if (!__any(bucket >= 0)) continue;   // wave-uniform: nothing listed in this row of the tile
-		CbcaListEntry e;
-		if (FILL && bucket >= 0) {
-			// the entry's shape: lengths of its rows, top to bottom (all listed lanes of the row together)
-			e.id = id;
-			const uint32_t own = bytemin4(p0[y * W + x], p1[y * W + x + sh]);
-			const int u = (int)((own >> 16) & 0xff), dn = (int)(own >> 24);
-			unsigned long long lo = (unsigned long long)((u & 15) | ((dn & 15) << 4));   // bytes 0..7 of the 12
-			uint32_t hi = 0;                                                               // bytes 8..11
-			bool shape = u + dn + 1 <= 9;
-			if (shape) {
-				for (int k = 0; k <= u + dn; ++k) {
-					const int g = (y - u + k) * W + x;
-					const uint32_t mm = k == u ? own : bytemin4(p0[g], p1[g + sh]);
-					const uint32_t l = mm & 0xff, r = (mm >> 8) & 0xff;
-					shape = shape && l <= 15 && r <= 15;
-					const uint32_t byte = (l & 15u) | ((r & 15u) << 4);
-					if (k < 7) lo |= (unsigned long long)byte << (8 * (k + 1));
-					else hi |= byte << (8 * (k - 7));
-				}
-			}
-			e.w[0] = (uint32_t)lo; e.w[1] = (uint32_t)(lo >> 32); e.w[2] = shape ? hi : CL_NOSHAPE;
-		}
-#pragma unroll
-		for (int b = 0; b < CL_BUCKETS; ++b) {
-			const unsigned long long m = __ballot(bucket == b);
-			if (m == 0) continue;   // wave-uniform
-			const int leader = __builtin_ctzll(m);
-			uint32_t start = 0;
-			if (lane == leader) start = atomicAdd(&cur[b], (uint32_t)__builtin_popcountll(m));
-			if (FILL) {
-				start = (uint32_t)__builtin_amdgcn_readlane((int)start, leader);
-				const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-				if (bucket == b) list[start + rank] = e;
-			}
-		}
-	}
-	if (!FILL) {
-		__syncthreads();
-		if (threadIdx.x < CL_BUCKETS) hdr->block[blockIdx.x][threadIdx.x] = cur[threadIdx.x];
-	}
-}
-
-// counts -> first positions: block after block (a block's tiles are one compact region of the volume, so that region's
-// entries are consecutive in the list and meet in one L2), inside a block class after class (the 64 consecutive entries
-// of a wave are of one size class except at the few class boundaries)
-__global__ void __launch_bounds__(256) cbca_list_scan_kernel(CbcaListHdr *__restrict__ hdr)
-{
-	constexpr int PER = CL_BLOCKS / 256;
-	__shared__ uint32_t part[256];
-	uint32_t mine = 0;
-	for (int k = threadIdx.x * PER; k < (threadIdx.x + 1) * PER; ++k)
-		for (int b = 0; b < CL_BUCKETS; ++b) mine += hdr->block[k][b];
-	part[threadIdx.x] = mine;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t run = 0;
-		for (int t = 0; t < 256; ++t) {
-			const uint32_t n = part[t];
-			part[t] = run;
-			run += n;
-		}
-		hdr->total = run;
-	}
-	__syncthreads();
-	uint32_t run = part[threadIdx.x];
-	for (int k = threadIdx.x * PER; k < (threadIdx.x + 1) * PER; ++k) {
-		for (int b = 0; b < CL_BUCKETS; ++b) {
-			const uint32_t n = hdr->block[k][b];
-			hdr->block[k][b] = run;
-			run += n;
-		}
-	}
-}
-
-// unsigned 32-bit division by a launch-time constant: q = (t + ((n - t) >> 1)) >> (s - 1), t = umulhi(n, M)
-struct ClDiv { uint32_t M, s1; };
-static ClDiv cl_div_make(uint32_t dv)   // dv >= 2
-{
-	uint32_t s = 0;
-	while (((uint64_t)1 << s) < dv) ++s;
-	ClDiv r;
-	r.M = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << s) - dv)) / dv + 1);
-	r.s1 = s - 1;
-	return r;
-}
-__device__ __forceinline__ uint32_t cl_div(uint32_t n, ClDiv dv)
-{
-	const uint32_t t = __umulhi(n, dv.M);
-	return (t + ((n - t) >> 1)) >> dv.s1;
-}
-
-// one lane per list entry; the reference's loop (adcensus.cu:356-373) with the lengths from the packed maps.  The lanes
-// of a wave hold supports of one size class, so they leave the loops together.  Most entries are small supports whose
-// cost is per-entry and per-row overhead, not additions: the voxel index is split with multiplications, the next row's
-// lengths are fetched before the current row is summed, a run of up to 8 / 16 values is fetched whole with two / four
-// 16-byte loads (dword-aligned: the run starts anywhere; values behind the run's end are fetched but never added) and
-// longer runs 16 values at a time.
-typedef float cl_f4u __attribute__((ext_vector_type(4), aligned(4)));   // four floats at any dword address
-
-template <bool NT>
-__global__ void __launch_bounds__(256) cbca_list_kernel(const CbcaListEntry *__restrict__ list, const CbcaListHdr *__restrict__ hdr, const CbcaArgs A,
-                                                        const ClDiv divHW, const ClDiv divW)
-{
-	const uint32_t total = hdr->total;
-	const int H = A.H, W = A.W, HWi = H * W;
-	const uint32_t nvox = (uint32_t)A.D * (uint32_t)HWi;
-	// the grid takes the list in windows of gridDim.x chunks of 256 entries; inside a window the blocks of one XCD
-	// (blockIdx % 8) take CONSECUTIVE chunks, so that neighbouring supports meet in one L2
-	const uint32_t stride = gridDim.x * 256u;
-	const uint32_t slot = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-	for (uint32_t i = slot * 256u + threadIdx.x; i < total; i += stride) {
-		const cb_u4 ent = *(const cb_u4 *)&list[i];
-		const uint32_t id = ent.x;
-		const uint32_t d = cl_div(id, divHW);
-		const uint32_t rem = id - d * (uint32_t)HWi;
-		const int y = (int)cl_div(rem, divW), x = (int)rem - y * W;
-		const float *__restrict__ plane = A.vin + (size_t)d * HWi;
-		const uint32_t vbase = d * (uint32_t)HWi;
-		float sum = 0;
-		int cnt = 0;
-		// n values of the run that starts at element ro of the plane
-		auto add_run = [&](int ro, int n) {
-			const float *__restrict__ row = plane + ro;
-			// 16 floats from the run's start stay inside the volume (the last rows of the last plane take the exact path)
-			const bool whole = n <= 16 && vbase + (uint32_t)ro + 16u <= nvox;
-			if (whole) {
-				const cl_f4u v0 = *(const cl_f4u *)row;
-				cl_f4u v1 = cl_f4u{0.0f, 0.0f, 0.0f, 0.0f};
-				if (n > 4) v1 = *(const cl_f4u *)(row + 4);   // (a lane whose run ends inside the first 16 bytes issues no second access)
-				const float a[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-				for (int t = 0; t < 8; ++t) sum += t < n ? a[t] : -0.0f;   // x + (-0.0f) == x: the values behind the run are no operands
-				if (n > 8) {
-					const cl_f4u v2 = *(const cl_f4u *)(row + 8), v3 = *(const cl_f4u *)(row + 12);
-					const float b[8] = {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-#pragma unroll
-					for (int t = 0; t < 8; ++t) sum += 8 + t < n ? b[t] : -0.0f;
-				}
-			} else {
-				int k = 0;
-				for (; k + 16 <= n; k += 16) {
-					cl_f4u v[4];
-#pragma unroll
-					for (int t = 0; t < 4; ++t) v[t] = *(const cl_f4u *)(row + k + 4 * t);
-#pragma unroll
-					for (int t = 0; t < 4; ++t) { sum += v[t].x; sum += v[t].y; sum += v[t].z; sum += v[t].w; }
-				}
-				if (k + 8 <= n) {
-					const cl_f4u v0 = *(const cl_f4u *)(row + k), v1 = *(const cl_f4u *)(row + k + 4);
-					sum += v0.x; sum += v0.y; sum += v0.z; sum += v0.w;
-					sum += v1.x; sum += v1.y; sum += v1.z; sum += v1.w;
-					k += 8;
-				}
-				if (k + 4 <= n) {
-					const cl_f4u v0 = *(const cl_f4u *)(row + k);
-					sum += v0.x; sum += v0.y; sum += v0.z; sum += v0.w;
-					k += 4;
-				}
-				if (k < n) {   // 1 .. 3 left: single loads (a 16-byte load could reach past the end of the volume)
-					const float a0 = row[k], a1 = row[min(k + 1, n - 1)], a2 = row[min(k + 2, n - 1)];
-					sum += a0;
-					if (k + 1 < n) sum += a1;
-					if (k + 2 < n) sum += a2;
-				}
-			}
-			cnt += n;
-		};
-		if (!(ent.w & CL_NOSHAPE)) {
-			// the shape travels with the entry: no length loads at all
-			const int u = (int)(ent.y & 15u), dn = (int)((ent.y >> 4) & 15u);
-			uint32_t w0 = ent.y >> 8, w1 = ent.z, w2 = ent.w;   // a byte per row, next row = low byte
-			for (int q = y - u; q <= y + dn; ++q) {
-				const int l = (int)(w0 & 15u), r = (int)((w0 >> 4) & 15u);
-				w0 = (w0 >> 8) | (w1 << 16);   // 24 + 32 + 32 bits shifted right by a byte
-				w1 = (w1 >> 8) | (w2 << 24);
-				w2 >>= 8;
-				add_run(q * W + x - l, l + r + 1);
-			}
-		} else {
-			const int sh = (int)d * A.direction;
-			const uint32_t *__restrict__ q0 = A.p0 + x, *__restrict__ q1 = A.p1 + x + sh;
-			const uint32_t own = bytemin4(q0[y * W], q1[y * W]);
-			const int u = (int)((own >> 16) & 0xff), dn = (int)(own >> 24);
-			uint32_t nxt = bytemin4(q0[(y - u) * W], q1[(y - u) * W]);
-			for (int q = y - u; q <= y + dn; ++q) {
-				const uint32_t mm = nxt;
-				const int qn = min(q + 1, y + dn);
-				nxt = bytemin4(q0[qn * W], q1[qn * W]);   // the next row's lengths travel while this row is summed
-				const int l = (int)(mm & 0xff), r = (int)((mm >> 8) & 0xff);
-				add_run(q * W + x - l, l + r + 1);
-			}
-		}
-		const float res = sum / (float)cnt;
-		if (NT) __builtin_nontemporal_store(res, A.vout + id);
-		else A.vout[id] = res;
-	}
-}
-
-// header + one 16-byte entry per output (worst case: every output is listed) + one class byte per voxel
-static size_t cl_list_entries(int D, int H, int W) { return ((size_t)D * H * W + 63) & ~(size_t)63; }
-size_t cbca_list_bytes(int D, int H, int W)
-{
-	return (sizeof(CbcaListHdr) + cl_list_entries(D, H, W) * sizeof(CbcaListEntry) + (size_t)D * H * W + 255) & ~(size_t)255;
-}
-
-// classification of a (pair, direction): which outputs the list kernel owns, sorted by support size.  Arms <= 254 and
-// D*H*W < 2^31 required (callers check).
-int cbca_list_build(const void *packed, void *listmem, int D, int H, int W, int direction, hipStream_t st)
-{
-	const CbcaScratch cs = cbca_scratch(packed, H, W);
-	CbcaListHdr *hdr = (CbcaListHdr *)listmem;
-	CbcaListEntry *list = (CbcaListEntry *)((char *)listmem + sizeof(CbcaListHdr));
-	uint8_t *cls = (uint8_t *)(list + cl_list_entries(D, H, W));
-	const dim3 grid(CL_BLOCKS), block(256);
-	hipLaunchKernelGGL((cbca_list_build_kernel<false>), grid, block, 0, st, cs.p0, cs.p1, hdr, list, cls, D, H, W, direction);
-	hipLaunchKernelGGL(cbca_list_scan_kernel, dim3(1), dim3(256), 0, st, hdr);
-	hipLaunchKernelGGL((cbca_list_build_kernel<true>), grid, block, 0, st, cs.p0, cs.p1, hdr, list, cls, D, H, W, direction);
-	return check_launch("cbca_list_build");
-}
-
 size_t cbca_scratch_bytes(int H, int W) { return (((size_t)2 * H * W + 3 * CS_PAD + CS_FLAGS) * sizeof(uint32_t) + 255) & ~(size_t)255; }
 
 int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, hipStream_t st)
@@ -948,12 +403,13 @@ int cbca_pack(const float *x0c, const float *x1c, void *scratch, int H, int W, h
 		set_error("cbca_pack: %s", hipGetErrorString(e));
 		return (int)e;
 	}
-	hipLaunchKernelGGL(cbca_pack_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, x0c, p0, H, W, flag);
-	hipLaunchKernelGGL(cbca_pack_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, x1c, p1, H, W, flag);
+	hipLaunchKernelGGL(cbca_pack_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, x0c, p0, H, W, flag, 0);
+	hipLaunchKernelGGL(cbca_pack_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, x1c, p1, H, W, flag, 1);
+	hipLaunchKernelGGL(cbca_route_kernel, dim3(1), dim3(1), 0, st, flag, HW);
 	return check_launch("cbca_pack");
 }
 
-// v1 kernel that runs only when cbca_pack flagged a saturated arm (and the tiled kernel therefore stood down)
+// v1 kernel that runs only when cbca_pack saw an arm the packed form cannot hold (and the other kernels therefore stood down)
 int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, const float *vin, float *vout, int D, int H, int W,
                      int direction, hipStream_t st)
 {
@@ -963,11 +419,10 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
 	return check_launch("cbca (overflow path)");
 }
 
-// max_arm: largest arm length that can occur (L1-1 when L1 is known, else < 0: the pack kernel's overflow flag decides).
-// Arm lengths saturate at 255 in the packed form: callers route max_arm > 254 to the direct kernel.
+// route >= 0 (the caller does not know the arms): the launch stands down unless cbca_pack's route word equals it.
 // cfg (mc_common.h): rows per strip, cache policy and plane range; zero / negative fields = derived from the size.
-int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm, hipStream_t st,
-                const CbcaCfg &cfg, const void *listmem)
+int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int route, hipStream_t st,
+                const CbcaCfg &cfg)
 {
 	const int d0 = cfg.nd > 0 ? cfg.d0 : 0, nd = cfg.nd > 0 ? cfg.nd : D;
 	CbcaArgs A;
@@ -976,7 +431,8 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	A.vin = vin; A.vout = vout;
 	A.D = D; A.H = H; A.W = W; A.direction = direction;
 	A.d0 = d0; A.nd = nd;
-	A.overflow = max_arm < 0 ? cs.flag : nullptr;  // unknown arm bound: honour cbca_pack's flag
+	A.flags = route >= 0 ? cs.flag : nullptr;
+	A.route = route;
 	A.gx = (int)cdiv(W, CS_STEP);
 	// output rows per strip: 40 (5 % of halo rows) unless that leaves fewer than ~16 K waves -- at KITTI size (5 strips x
 	// 228 planes) 27 and 20 rows measured 5 % faster than 40, 53 rows 18 % slower
@@ -987,39 +443,9 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	const int64_t waves = (int64_t)cdiv((int64_t)A.gx * A.gy, 8) * 8 * cdiv(nd, 4) * 4;
 	// non-temporal volume accesses for volumes far larger than the 256 MB Infinity Cache (see cbca_strip_kernel)
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
-	// short arms (L1 <= 5, the KITTI parameter sets): every lane walks its own supports out of 9-row rings; on a Gaussian
-	// texture it is within 8 % of the strip kernel, on real-scene arm statistics 4.6 x faster.  With the arm bound unknown
-	// (the standalone operator) both kernels are launched and cbca_pack's second flag word lets exactly one of them run.
-	const bool by_arm = cfg.form == 0 && max_arm < 0 && !listmem;
-	const bool window = cfg.form == 2 || (cfg.form == 0 && max_arm >= 0 && max_arm <= CW_ARM) || by_arm;
-	A.by_arm = by_arm ? 1 : 0;
-	if (window) {
-		CbcaArgs B = A;
-		B.gx = (int)cdiv(W, CW_STEP);
-		const int64_t gy_w = cdiv((int64_t)16384, (int64_t)B.gx * nd);
-		B.rb = cfg.rb > 0 ? cfg.rb : (int)std::min<int64_t>(40, std::max<int64_t>(16, cdiv((int64_t)H, gy_w)));
-		B.gy = (int)cdiv(H, B.rb);
-		const int64_t wv = (int64_t)cdiv((int64_t)B.gx * B.gy, 8) * 8 * cdiv(nd, CW_WAVES) * CW_WAVES;
-		if (nt) hipLaunchKernelGGL((cbca_window_kernel<true>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, B);
-		else hipLaunchKernelGGL((cbca_window_kernel<false>), dim3((unsigned)cdiv(wv, CW_WAVES)), dim3(64 * CW_WAVES), 0, st, B);
-		if (!by_arm) return check_launch("cbca_window");
-	}
 	// prefetch 2 rows, ring of 4 rows, 1 row of look-ahead, window form +-2 columns (+-4 measured slower at KITTI and 1000x1500)
-	if (listmem) {
-		// the pair's list (cbca_list_build) owns the supports that do not fit the window form; the list kernel follows on
-		// the same stream and overwrites the provisional values the strip kernel stored for them
-		if (nt) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true, true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
-		else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, false, true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
-		const CbcaListHdr *hdr = (const CbcaListHdr *)listmem;
-		const CbcaListEntry *list = (const CbcaListEntry *)((const char *)listmem + sizeof(CbcaListHdr));
-		const dim3 lgrid(256 * 8);   // persistent: 8 blocks per CU stride over the list
-		const ClDiv dHW = cl_div_make((uint32_t)H * (uint32_t)W), dW = cl_div_make((uint32_t)W);
-		if (nt) hipLaunchKernelGGL((cbca_list_kernel<true>), lgrid, dim3(256), 0, st, list, hdr, A, dHW, dW);
-		else hipLaunchKernelGGL((cbca_list_kernel<false>), lgrid, dim3(256), 0, st, list, hdr, A, dHW, dW);
-		return check_launch("cbca_strip + cbca_list");
-	}
-	if (nt) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
-	else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, false, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+	if (nt) hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+	else hipLaunchKernelGGL((cbca_strip_kernel<2, 4, 1, 2, false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
 	return check_launch("cbca_strip");
 }
 

@@ -27,8 +27,8 @@ struct CbcaArgs {
 	float *vout;
 	int D, H, W, direction;
 	int rb;                       // output rows per strip
-	const uint32_t *overflow;     // optional, cbca_pack's flags: [0] an arm saturated the packed form -> do nothing; [1] an arm > 4; [2] an arm > 13
-	int by_arm;                   // 1: flag [1] selects the kernel (window kernel iff no arm > 4, strip kernel otherwise)
+	const uint32_t *flags;        // optional, cbca_pack's flag words: the launch runs only if cbca_gate(flags, route)
+	int route;
 	int gx, gy;                   // strips per row, row chunks
 	int d0, nd;                   // planes [d0, d0 + nd) of the volume are processed by this launch
 };
@@ -39,7 +39,33 @@ constexpr int CS_COLS = 256;
 constexpr int CS_STEP = 252;   // output columns per strip
 constexpr int CS_PAD = 1024;   // words of padding around p0 / p1 in the scratch (shifted dwordx4 reads may start outside)
 
-constexpr int CS_FLAGS = 4;    // flag words behind the packed lengths (three used)
+// flag words behind the packed lengths, written by cbca_pack: what the pair's arms look like and the kernel they call for
+constexpr int CS_FLAGS = 8;
+enum { CF_SATURATED = 0,      // an arm longer than 254 pixels (the packed form saturates): one thread per voxel
+       CF_ARM_GT4 = 1, CF_ARM_GT13 = 2, CF_ROUTE = 3,
+       CF_UNIT_PIXELS = 4 };  // [4], [5]: pixels of image 0 / 1 whose four arms are all <= 1
+enum { CR_TILE4 = 0,          // every arm <= 4 (L1 <= 5): tile kernel, short-arm instance
+       CR_TILE13 = 1,         // every arm <= 13 (L1 <= 14), real-scene statistics: tile kernel, long-arm instance
+       CR_STRIP = 2,          // longer arms, or nearly every support the minimal 3 x 3 (textures): strip kernel
+       CR_DIRECT = 3,         // saturated packed form
+       // launch conditions that are not a single route (CbcaArgs::route):
+       CR_ARMS_LE4 = 16, CR_ARMS_LE13 = 17,   // the forced tile instances of the test hook: any pair whose arms fit
+       CR_NOT_DIRECT = 18,                    // the forced strip kernel: any pair the packed form holds
+       CR_STRIP_OR_TILE13 = 19 };             // strip kernel where L1 > 14 is known: the routes of longer arms and of arms <= 13 alike
+
+// does this launch run? (flags == nullptr: the caller knows the arms and launched exactly the right kernel)
+__device__ __forceinline__ bool cbca_gate(const uint32_t *__restrict__ flags, int route)
+{
+	if (!flags) return true;
+	const uint32_t r = flags[CF_ROUTE];
+	switch (route) {
+	case CR_ARMS_LE4: return !flags[CF_ARM_GT4];
+	case CR_ARMS_LE13: return !flags[CF_ARM_GT13];
+	case CR_NOT_DIRECT: return r != CR_DIRECT;
+	case CR_STRIP_OR_TILE13: return r == CR_STRIP || r == CR_TILE13;
+	default: return r == (uint32_t)route;
+	}
+}
 
 // scratch = [pad | p0 (H*W) | pad | p1 (H*W) | pad | CS_FLAGS flag words], pad = CS_PAD words
 size_t cbca_scratch_bytes(int H, int W);   // cbca.hip

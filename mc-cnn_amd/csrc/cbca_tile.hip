@@ -1,5 +1,5 @@
-// Cross-based cost aggregation (adcensus.cu:343-377) for real-scene arm statistics: LDS tiles, supports sorted by height
-// inside a tile, vertical run sharing.
+// Cross-based cost aggregation (adcensus.cu:343-377) for real-scene arm statistics: column strips streamed through an LDS
+// ring, supports sorted by height inside a step, vertical run sharing.
 //
 // The reference's region sum is ONE serial chain of fp32 additions per output -- rows ascending, inside a row x ascending --
 // and that order is kept (cbca.hip, parity rule).  What can be shared without touching the order: the horizontal run of
@@ -8,19 +8,30 @@
 // first row to its own last row.  A lane therefore owns an ITEM = one column x 4 consecutive output rows: it walks the rows
 // from the topmost first row to the bottommost last row of its four outputs, fetches every run value ONCE from LDS and
 // adds it to all four accumulators; an accumulator is reset to +0.0 at its output's first row and read out after its last
-// row -- what it collected outside its own rows never reaches a result.  A value beyond a lane's own run length enters as
-// -0.0f (x + -0.0f == x exactly), so the lanes of a wave walk rows of different run lengths in lockstep.  Per tap and wave:
-// one ds_read_b32, one compare + select, four additions.
+// row -- what it collected outside its own rows never reaches a result.  A lane whose own run is shorter than the wave's longest
+// ... is masked off: the lanes of a wave walk rows of different run lengths in lockstep under a shrinking EXEC mask.  Per tap
+// and wave: one ds_read_b32, one compare, four additions.
 //
-// A block stages one tile of ONE disparity plane (TW x TH outputs + the arm halo) in LDS: values, per staged pixel the
-// run (4 * left, length), per output its (up, down).  A wave runs at the pace of its tallest item and longest runs, and
-// real scenes mix 3 x 3 supports with flat regions of (2 L1 - 1)^2 taps: the tile's items are SORTED by height (counting
-// sort in LDS, a few instructions per item) and the waves of the block pull 64-item chunks, tallest first, from a shared
-// counter.  Results go to an LDS tile and leave as full rows.
+// A block walks a strip of TW output columns of ONE disparity plane top to bottom in steps of TH rows.  An LDS ring of
+// TH + 2A rows holds the step's window: values (TW + the arm halo on either side), per pixel of the TW columns the run
+// (4 * left, length) and (up, down).  The TH rows the next step adds are fetched into registers before the step's work and
+// committed to the ring after it: every row of the plane is read once per strip and memory latency hides behind the
+// additions.  A wave runs at the pace of its tallest item and longest runs, and real scenes mix 3 x 3 supports with flat
+// regions of (2 L1 - 1)^2 taps: the step's items are SORTED by height (counting sort in LDS, a few instructions per item)
+// and the waves of the block pull 64-item chunks, tallest first, from a shared counter.  Results go to an LDS tile and
+// leave as full rows.
 #include "cbca_common.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace mc {
+
+#ifdef MC_TILE_PROF
+__device__ unsigned long long tile_prof[4096];
+#define TPROF(slot) do { if (prof_on && lane == 0) tile_prof[(step_no * 4 + wv_) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TPROF(slot) do { } while (0)
+#endif
 
 namespace {
 
@@ -28,318 +39,460 @@ template <int A, int TW, int TH>
 struct TileGeo {
 	static constexpr int AH = (A + 3) & ~3;           // horizontal halo, a multiple of 4 columns (16-byte rows)
 	static constexpr int SW = TW + 2 * AH;            // staged columns
-	static constexpr int SH = TH + 2 * A;             // staged rows
-	static constexpr int NI = TW * (TH / 4);          // items: column x 4 rows
-	static constexpr int NKEY = 2 * A + 4 + 1;        // item heights 0 .. 2A + 4
-	static constexpr int V_BYTES = SH * SW * 4;
-	static constexpr int M_BYTES = (SH * TW * 2 + 15) & ~15;   // runs: output columns only (a run is looked up in the item's own column)
-	static constexpr int UD_BYTES = TH * TW * 2;
+	static constexpr int RR = TH + 2 * A;             // ring rows: the window of one step
+	static constexpr int NI = TW * (TH / 4);          // items of a step: column x 4 rows
+	static constexpr int NG = NI / 64;                // groups of 64 consecutive items (one wave's worth)
+	static constexpr int NKEY = 32;                   // sort keys: 0 nothing to compute, 1 four 3 x 3 supports, height + 1 otherwise (<= 2A + 5)
+	static constexpr int V_BYTES = RR * SW * 4;
+	static constexpr int M_BYTES = (RR * TW * 2 + 15) & ~15;   // runs: output columns only (a run is looked up in the item's own column)
+	static constexpr int UD_BYTES = (RR * TW + 15) & ~15;      // up | down << 4 per pixel, 0xff = no output here
 	static constexpr int OUT_BYTES = TH * TW * 4;
 	static constexpr int TAB_BYTES = NI * 2;
-	static constexpr int MISC_BYTES = 2 * 64 * 4 + 16;
+	static constexpr int MISC_BYTES = NG * NKEY * 4 + 16;   // items per group and key; chunk counter
 	static constexpr int LDS_BYTES = V_BYTES + M_BYTES + UD_BYTES + OUT_BYTES + TAB_BYTES + MISC_BYTES;
 };
 
-// NQ tap slots of a row: every lane fetches NQ values from its run's start (the values behind its own run are fetched
-// and never added), then  sum_j += t < n ? v[t] : -0.0f  for its four accumulators
-template <int NQ>
-__device__ __forceinline__ void tile_taps(const float *__restrict__ p, int n, float (&sum)[4])
+// The taps of one support row for the four accumulators of a lane.  Lane-private run: n values from LDS address p.  The
+// lanes of a wave hold runs of different lengths, so tap t is added under  EXEC &= (t < n)  (v_cmpx narrows EXEC, the run
+// is a prefix, so EXEC only ever shrinks inside a row): one compare and four additions per tap and wave, a lane whose run
+// is over is simply masked off (its accumulators keep their values: no operand at all), and the row ends -- s_cbranch_execz
+// after every group -- when the wave's longest run does.  Values are fetched nine at a time (0..8 up front: most rows
+// end there); rows with longer runs fetch 9..17 and 18..26 when they get there.  hipcc cannot express the EXEC narrowing,
+// hence the assembly; it waits for its own LDS reads (lgkmcnt(0)) before it uses them and restores EXEC.
+#define MC_TAP(t, v) "v_cmpx_lt_u32_e32 vcc, " #t ", %[n]\n v_add_f32 %[s0], %[s0], %[" #v "]\n v_add_f32 %[s1], %[s1], %[" #v "]\n" \
+                     " v_add_f32 %[s2], %[s2], %[" #v "]\n v_add_f32 %[s3], %[s3], %[" #v "]\n"
+#define MC_LOAD9(o) "ds_read_b32 %[v0], %[p] offset:" #o "+0\n ds_read_b32 %[v1], %[p] offset:" #o "+4\n ds_read_b32 %[v2], %[p] offset:" #o "+8\n" \
+                    " ds_read_b32 %[v3], %[p] offset:" #o "+12\n ds_read_b32 %[v4], %[p] offset:" #o "+16\n ds_read_b32 %[v5], %[p] offset:" #o "+20\n" \
+                    " ds_read_b32 %[v6], %[p] offset:" #o "+24\n ds_read_b32 %[v7], %[p] offset:" #o "+28\n ds_read_b32 %[v8], %[p] offset:" #o "+32\n"
+#define MC_EXIT "s_nop 1\n s_cbranch_execz .Ltaps_done_%=\n"
+template <bool LONG>   // LONG: runs up to 27 values (arms <= 13), else up to 9 (arms <= 4)
+__device__ __forceinline__ void tile_taps(const float *p, int n, float (&sum)[4])
 {
-	float v[NQ];
-#pragma unroll
-	for (int t = 0; t < NQ; ++t) v[t] = p[t];
-#pragma unroll
-	for (int t = 0; t < NQ; ++t) {
-		const float tv = t < n ? v[t] : -0.0f;
-		sum[0] += tv; sum[1] += tv; sum[2] += tv; sum[3] += tv;
+	float v0, v1, v2, v3, v4, v5, v6, v7, v8;
+	unsigned long long sv;
+	const unsigned pa = (unsigned)(size_t)p;   // LDS byte address
+	if (LONG) {
+		asm volatile("s_mov_b64 %[sv], exec\n" MC_LOAD9(0) "s_waitcnt lgkmcnt(0)\n"
+		             MC_TAP(0, v0) MC_TAP(1, v1) MC_TAP(2, v2) MC_EXIT MC_TAP(3, v3) MC_TAP(4, v4) MC_EXIT
+		             MC_TAP(5, v5) MC_TAP(6, v6) MC_TAP(7, v7) MC_TAP(8, v8) MC_EXIT
+		             MC_LOAD9(36) "s_waitcnt lgkmcnt(0)\n"
+		             MC_TAP(9, v0) MC_TAP(10, v1) MC_TAP(11, v2) MC_TAP(12, v3) MC_EXIT MC_TAP(13, v4) MC_TAP(14, v5) MC_TAP(15, v6) MC_TAP(16, v7) MC_TAP(17, v8) MC_EXIT
+		             MC_LOAD9(72) "s_waitcnt lgkmcnt(0)\n"
+		             MC_TAP(18, v0) MC_TAP(19, v1) MC_TAP(20, v2) MC_TAP(21, v3) MC_TAP(22, v4) MC_EXIT MC_TAP(23, v5) MC_TAP(24, v6) MC_TAP(25, v7) MC_TAP(26, v8)
+		             ".Ltaps_done_%=:\n s_mov_b64 exec, %[sv]\n"
+		             : [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3]), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2),
+		               [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7), [v8] "=&v"(v8), [sv] "=&s"(sv)
+		             : [n] "v"(n), [p] "v"(pa)
+		             : "vcc", "memory");
+	} else {
+		asm volatile("s_mov_b64 %[sv], exec\n" MC_LOAD9(0) "s_waitcnt lgkmcnt(0)\n"
+		             MC_TAP(0, v0) MC_TAP(1, v1) MC_TAP(2, v2) MC_EXIT MC_TAP(3, v3) MC_TAP(4, v4) MC_EXIT
+		             MC_TAP(5, v5) MC_TAP(6, v6) MC_TAP(7, v7) MC_TAP(8, v8)
+		             ".Ltaps_done_%=:\n s_mov_b64 exec, %[sv]\n"
+		             : [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3]), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2),
+		               [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7), [v8] "=&v"(v8), [sv] "=&s"(sv)
+		             : [n] "v"(n), [p] "v"(pa)
+		             : "vcc", "memory");
 	}
 }
+#undef MC_TAP
+#undef MC_LOAD9
+#undef MC_EXIT
 
 }  // namespace
 
+// P.gx x P.gy regions of TW columns x P.rb rows (a multiple of TH); a block takes one (region, plane)
 template <int A, int TW, int TH, int NWAVES, bool NT>
-__global__ void __launch_bounds__(64 * NWAVES) cbca_tile_kernel(const CbcaArgs P, const int tiles_x, const int tiles_per_plane,
-                                                                const int gate)
+__global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : 1) cbca_tile_kernel(const CbcaArgs P)
 {
 	using G = TileGeo<A, TW, TH>;
-	constexpr int AH = G::AH, SW = G::SW, SH = G::SH, NI = G::NI, NKEY = G::NKEY;
+	constexpr int AH = G::AH, SW = G::SW, RR = G::RR, NI = G::NI, NKEY = G::NKEY;
 	constexpr int NTHREADS = 64 * NWAVES;
 	constexpr int VOL_AUX = NT ? 2 : 0;
-	static_assert(TH % 4 == 0 && TW % 4 == 0 && TW <= 256 && TH / 4 <= 256 && NKEY <= 64, "tile geometry");
+	constexpr int NG = G::NG;
+	static_assert(TH % 4 == 0 && TW % 64 == 0 && TW <= 256 && TH / 4 <= 256 && 2 * A + 5 < NKEY && A <= 15 && NG % NWAVES == 0, "tile geometry");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	float *__restrict__ Vl = (float *)smem;
 	unsigned short *__restrict__ Ml = (unsigned short *)(smem + G::V_BYTES);
-	unsigned short *__restrict__ UDl = (unsigned short *)(smem + G::V_BYTES + G::M_BYTES);
+	unsigned char *__restrict__ UDl = smem + G::V_BYTES + G::M_BYTES;
 	float *__restrict__ OUTl = (float *)(smem + G::V_BYTES + G::M_BYTES + G::UD_BYTES);
 	unsigned short *__restrict__ TABl = (unsigned short *)(smem + G::V_BYTES + G::M_BYTES + G::UD_BYTES + G::OUT_BYTES);
-	cb_u32 *__restrict__ HISTl = (cb_u32 *)(smem + G::V_BYTES + G::M_BYTES + G::UD_BYTES + G::OUT_BYTES + G::TAB_BYTES);
-	cb_u32 *__restrict__ BASEl = HISTl + 64;
-	cb_u32 *__restrict__ CTRl = BASEl + 64;   // [0] next chunk, [1] / [2] the tile's largest up / down arm
+	cb_u32 *__restrict__ GHl = (cb_u32 *)(smem + G::V_BYTES + G::M_BYTES + G::UD_BYTES + G::OUT_BYTES + G::TAB_BYTES);   // [group][key]
+	cb_u32 *__restrict__ CTRl = GHl + NG * NKEY;   // [0] next chunk
 
-	// cbca_pack's flags (arm bound unknown to the caller): [0] an arm saturated the packed form, [1] an arm > 4, [2] an arm > 13.
-	// gate bit 0: run only if no arm > 4; bit 1: only if some arm > 4; bit 2: only if no arm > 13
-	if (P.overflow) {
-		if (P.overflow[0]) return;
-		if ((gate & 1) && P.overflow[1]) return;
-		if ((gate & 2) && !P.overflow[1]) return;
-		if ((gate & 4) && P.overflow[2]) return;
-	}
-	const int tid = threadIdx.x, lane = tid & 63;
+	if (!cbca_gate(P.flags, P.route)) return;   // (the pair's arms call for another kernel)
+	const int tid0 = threadIdx.x;
+	const int tid = tid0, lane = tid & 63;
+	const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: per-row store descriptors stay in SGPRs
 	const int H = P.H, W = P.W;
 	const int HWi = H * W;
-	// block -> (plane, tile): the blocks of one XCD (blockIdx % 8) take every 8th plane and walk its tiles in row-major
-	// order, so the halo a tile shares with its neighbours is met in that XCD's L2
+	// block -> (region, plane): the blocks of one XCD (blockIdx % 8) walk all planes of a region before the next region, so
+	// the region's packed lengths (left: identical for every d, right: windows shifted by d) are fetched from HBM once per
+	// XCD and served by its L2 for the other planes
 	const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-	const int d = P.d0 + (s / tiles_per_plane) * 8 + xcd;
-	if (d >= P.d0 + P.nd) return;
-	const int tin = s % tiles_per_plane;
-	const int tx0 = (tin % tiles_x) * TW, ty0 = (tin / tiles_x) * TH;
+	const int region = (s / P.nd) * 8 + xcd;
+	const int d = P.d0 + s % P.nd;
+	if (region >= P.gx * P.gy) return;
+	const int cx = region % P.gx, cy = region / P.gx;
+	const int tx0 = cx * TW, ys = cy * P.rb, ye = min(H, ys + P.rb);
 	const int sh = d * P.direction;
-	const int sx0 = tx0 - AH, sy0 = ty0 - A;
+	const int sx0 = tx0 - AH, yr0 = ys - A;   // image column / row of the ring's column 0 / relative row 0
 	const cb_u32 OOB = 0x80000000u;
 	const int plane_bytes = HWi * 4;
 	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(P.vin + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
-	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(P.vout + (size_t)d * HWi), 0, plane_bytes, 0x00020000);
 	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
 	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(P.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(P.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
 
-	if (tid < 64) HISTl[tid] = 0;
-	if (tid == 0) { CTRl[0] = 0; CTRl[1] = 0; CTRl[2] = 0; }
-	__syncthreads();
+	for (int q = tid; q < NG * NKEY; q += NTHREADS) GHl[q] = 0;
+	if (tid == 0) CTRl[0] = 0;
 
-	// ---- stage the tile ----------------------------------------------------------------------------------------------
-	// (a) the arm lengths of the OUTPUT rows: runs, (up, down), and the tile's largest up / down arm -- only the rows some
-	// output of this tile reaches are staged in (b): textured tiles stage a few halo rows, flat ones up to A on either side
-	constexpr int UB = 4;          // loads in flight per thread and batch
-	constexpr int APR = TW / 4;    // 4-column units per row of output columns
-	auto col_ok = [&](int xc) { return xc >= 0 && xc < W && xc + sh >= 0 && xc + sh < W; };   // pixel exists, partner inside the image (adcensus.cu:353)
-	auto arms_rows = [&](int rfirst, int nrows, int rskip0, int rskip1, bool outputs) {   // staged rows [rfirst, rfirst + nrows) except [rskip0, rskip1)
-		int umax = 0, dmax = 0;
-		const int nskip = max(0, rskip1 - rskip0);
-		const int n = (nrows - nskip) * APR;
-		for (int q0 = tid; q0 < n; q0 += NTHREADS * UB) {
-			cb_u4 a[UB], b[UB];
+	// ---- rows in flight: TH rows of values (all staged columns) and packed lengths (output columns) per thread -------
+	constexpr int UPR = SW / 4, APR = TW / 4;   // 4-column units per row
+	constexpr int NV = (TH * UPR + NTHREADS - 1) / NTHREADS, NA = (TH * APR + NTHREADS - 1) / NTHREADS;
+	struct Rows { cb_u4 v[NV], a[NA], b[NA]; };
+	const int ylast = min(H, ye + A);   // rows from here on are never needed
+	// relative rows rr0 .. rr0 + nrows - 1 (relative row rr = image row yr0 + rr) -> registers; rows outside the image: zeros
+	auto fetch_rows = [&](Rows &R, int rr0, int nrows, int tid) {
 #pragma unroll
-			for (int k = 0; k < UB; ++k) {
-				const int q = q0 + k * NTHREADS;
-				int r = rfirst + q / APR;
-				if (r >= rskip0) r += nskip;
-				const int u = q % APR;
-				const int y = sy0 + r, x = tx0 + 4 * u;
-				const bool rok = q < n && y >= 0 && y < H;
-				const int base = y * W + x;
-				// the padded scratch makes any in-row start readable; columns outside the image / the shifted range are masked below
-				a[k] = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
-				b[k] = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
-			}
-#pragma unroll
-			for (int k = 0; k < UB; ++k) {
-				const int q = q0 + k * NTHREADS;
-				if (q >= n) continue;
-				int r = rfirst + q / APR;
-				if (r >= rskip0) r += nskip;
-				const int u = q % APR;
-				const int y = sy0 + r, x = tx0 + 4 * u;
-				const bool rok = y >= 0 && y < H;
-				const cb_u32 mm[4] = {bytemin4(a[k].x, b[k].x), bytemin4(a[k].y, b[k].y), bytemin4(a[k].z, b[k].z), bytemin4(a[k].w, b[k].w)};
-				cb_u32 run[4], ud[4];
-#pragma unroll
-				for (int t = 0; t < 4; ++t) {
-					const bool ok = rok && col_ok(x + t);
-					const cb_u32 l = mm[t] & 0xffu, rr = (mm[t] >> 8) & 0xffu;
-					run[t] = ok ? ((4u * l) | ((l + rr + 1u) << 8)) : 0u;
-					ud[t] = ok ? (mm[t] >> 16) : 0xffffu;
-					if (outputs && ok) {
-						umax = max(umax, (int)((mm[t] >> 16) & 0xffu));
-						dmax = max(dmax, (int)(mm[t] >> 24));
-					}
-				}
-				*(cb_u2 *)(Ml + r * TW + 4 * u) = cb_u2{run[0] | (run[1] << 16), run[2] | (run[3] << 16)};
-				if (outputs) *(cb_u2 *)(UDl + (r - A) * TW + 4 * u) = cb_u2{ud[0] | (ud[1] << 16), ud[2] | (ud[3] << 16)};
-			}
+		for (int k = 0; k < NV; ++k) {
+			const int q = tid + k * NTHREADS;
+			const int r = q / UPR, u = q - r * UPR;
+			const int y = yr0 + rr0 + r, x = sx0 + 4 * u;
+			const bool rok = r < nrows && y >= 0 && y < ylast;
+			// one 16-byte load wherever the unit starts: columns left of the image read the end of the row above (or, before the
+			// plane, nothing), columns right of it the start of the row below (or, behind the plane, nothing) -- no run ever
+			// includes a column outside the image, so what those words hold is never an operand
+			R.v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)(y * W + x) * 4u : OOB, 0, VOL_AUX);
 		}
-		if (outputs) {
-			if (umax) atomicMax(&CTRl[1], (cb_u32)umax);
-			if (dmax) atomicMax(&CTRl[2], (cb_u32)dmax);
+#pragma unroll
+		for (int k = 0; k < NA; ++k) {
+			const int q = tid + k * NTHREADS;
+			const int r = q / APR, u = q - r * APR;
+			const int y = yr0 + rr0 + r, x = tx0 + 4 * u;
+			const bool rok = r < nrows && y >= 0 && y < ylast;
+			const int base = y * W + x;
+			// the padded scratch makes any in-row start readable; columns outside the image / the shifted range are masked at commit
+			R.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
+			R.b[k] = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
 		}
 	};
-	arms_rows(A, TH, 0, 0, true);
-	__syncthreads();
-	const int Umax = min((int)CTRl[1], A), Dmax = min((int)CTRl[2], A);
-	// (b) values of the rows the tile's outputs reach, lengths of the halo rows among them
-	arms_rows(A - Umax, Umax + TH + Dmax, A, A + TH, false);
-	{
-		constexpr int UPR = SW / 4;   // 4-column units per staged row
-		const int r0 = A - Umax, n = (Umax + TH + Dmax) * UPR;
-		for (int q0 = tid; q0 < n; q0 += NTHREADS * UB) {
-			cb_u4 v[UB];
+	// ... -> ring slots (slot0 = ring slot of relative row rr0)
+	auto commit_rows = [&](const Rows &R, int rr0, int slot0, int nrows, int tid) {
 #pragma unroll
-			for (int k = 0; k < UB; ++k) {
-				const int q = q0 + k * NTHREADS;
-				const int r = r0 + q / UPR, u = q % UPR;
-				const int y = sy0 + r, x = sx0 + 4 * u;
-				const bool rok = q < n && y >= 0 && y < H;
-				const int base = y * W + x;
-				if (x >= 0 && x + 3 < W) {
-					v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)base * 4u : OOB, 0, VOL_AUX);
-				} else {
-					cb_u32 t[4];
-#pragma unroll
-					for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_raw_buffer_load_b32(rv, (rok && x + e >= 0 && x + e < W) ? (cb_u32)(base + e) * 4u : OOB, 0, 0);
-					v[k] = cb_u4{t[0], t[1], t[2], t[3]};
-				}
-			}
-#pragma unroll
-			for (int k = 0; k < UB; ++k) {
-				const int q = q0 + k * NTHREADS;
-				if (q >= n) continue;
-				const int r = r0 + q / UPR, u = q % UPR;
-				*(cb_u4 *)(Vl + r * SW + 4 * u) = v[k];
-				const int orow = r - A, ocol = 4 * u - AH;
-				if (orow >= 0 && orow < TH && ocol >= 0 && ocol < TW) *(cb_u4 *)(OUTl + orow * TW + ocol) = v[k];   // adcensus.cu:353-354: outputs without a partner are copied through
-			}
+		for (int k = 0; k < NV; ++k) {
+			const int q = tid + k * NTHREADS;
+			const int r = q / UPR, u = q - r * UPR;
+			if (r >= nrows) continue;
+			int slot = slot0 + r;
+			slot = slot >= RR ? slot - RR : slot;
+			*(cb_u4 *)(Vl + slot * SW + 4 * u) = R.v[k];
 		}
+#pragma unroll
+		for (int k = 0; k < NA; ++k) {
+			const int q = tid + k * NTHREADS;
+			const int r = q / APR, u = q - r * APR;
+			if (r >= nrows) continue;
+			int slot = slot0 + r;
+			slot = slot >= RR ? slot - RR : slot;
+			const int y = yr0 + rr0 + r, x = tx0 + 4 * u;
+			const bool rok = y >= 0 && y < H;
+			const cb_u32 mm[4] = {bytemin4(R.a[k].x, R.b[k].x), bytemin4(R.a[k].y, R.b[k].y), bytemin4(R.a[k].z, R.b[k].z), bytemin4(R.a[k].w, R.b[k].w)};
+			cb_u32 run[4], ud[4];
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const int xc = x + t;
+				const bool ok = rok && xc < W && xc + sh >= 0 && xc + sh < W;   // pixel exists, partner inside the image (adcensus.cu:353)
+				const cb_u32 l = mm[t] & 0xffu, rr = (mm[t] >> 8) & 0xffu;
+				run[t] = ok ? ((4u * l) | ((l + rr + 1u) << 8)) : 0u;
+				ud[t] = ok ? (((mm[t] >> 16) & 15u) | ((mm[t] >> 20) & 0xf0u)) : 0xffu;
+			}
+			*(cb_u2 *)(Ml + slot * TW + 4 * u) = cb_u2{run[0] | (run[1] << 16), run[2] | (run[3] << 16)};
+			*(cb_u32 *)(UDl + slot * TW + 4 * u) = ud[0] | (ud[1] << 8) | (ud[2] << 16) | (ud[3] << 24);
+		}
+	};
+
+	Rows R;
+	for (int rr0 = 0; rr0 < RR; rr0 += TH) {   // the first step's window
+		const int nrows = min(TH, RR - rr0);
+		fetch_rows(R, rr0, nrows, tid);
+		commit_rows(R, rr0, rr0, nrows, tid);
 	}
 	__syncthreads();
 
-	// ---- items sorted by height (tallest first): counting sort --------------------------------------------------------
-	// item i = (column c, row group g): outputs rows 4g .. 4g+3 of column c; height = rows from the topmost first row to the
-	// bottommost last row of its outputs that have a partner
-	auto item_rows = [&](int c, int g, int (&s0)[4], int (&e0)[4], int &top, int &bot) {
-		top = 1 << 20; bot = -1;
+	int base = 0;   // ring slot of the step's first window row
+#ifdef MC_TILE_PROF
+	const int wv_ = tid >> 6;
+	int step_no = 0;
+#endif
+	if (ys + TH < ye) fetch_rows(R, RR, TH, tid);   // the rows the second step adds
+	for (int y0 = ys, rrn = RR; y0 < ye; y0 += TH, rrn += TH) {
+		const bool more = y0 + TH < ye;
+#ifdef MC_TILE_PROF
+		const bool prof_on = blockIdx.x == gridDim.x / 2 + 8 && step_no < 12;
+#endif
+		TPROF(0);
+		TPROF(1);
+
+		// ---- items sorted by height (tallest first): counting sort ----------------------------------------------------
+		// item i = (column c, row group g): outputs window rows A + 4g .. A + 4g + 3 of column c; height = rows from the topmost
+		// first row to the bottommost last row of its outputs that have a partner.  Window rows 0 .. RR - 1, ring slot of
+		// window row w = (base + w) mod RR.
+		auto item_rows = [&](int c, int g, int (&s0)[4], int (&e0)[4], int &top, int &bot) -> cb_u32 {
+			top = 1 << 20; bot = -1;
+			int slot = base + A + 4 * g;
+			cb_u32 udall = 0;
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const cb_u32 ud = UDl[(4 * g + j) * TW + c];
-			const bool ok = ud != 0xffffu;
-			const int up = (int)(ud & 0xffu), dn = (int)(ud >> 8);
-			s0[j] = ok ? 4 * g + j + A - up : 1 << 20;    // staged row of the output's first / last support row
-			e0[j] = ok ? 4 * g + j + A + dn : -1;
-			top = min(top, s0[j]);
-			bot = max(bot, e0[j]);
-		}
-	};
-	constexpr int IPT = (NI + NTHREADS - 1) / NTHREADS;
-	cb_u32 keyrank[IPT];
+			for (int j = 0; j < 4; ++j, ++slot) {
+				slot = slot >= RR ? slot - RR : slot;
+				const cb_u32 ud = UDl[slot * TW + c];
+				udall |= ud << (8 * j);
+				const bool ok = ud != 0xffu;
+				const int up = (int)(ud & 15u), dn = (int)(ud >> 4);
+				s0[j] = ok ? 4 * g + j + A - up : 1 << 20;    // window row of the output's first / last support row
+				e0[j] = ok ? 4 * g + j + A + dn : -1;
+				top = min(top, s0[j]);
+				bot = max(bot, e0[j]);
+			}
+			return udall;
+		};
+		// key of an item: 0 = nothing to compute, 1 = its four supports are all the minimal 3 x 3, else height + 1.  The sort is
+		// STABLE (ballot ranks inside a group of 64 consecutive columns, per-group counts, one scan): neighbouring columns of
+		// one class stay neighbouring lanes, so a chunk's LDS reads are mostly consecutive words.
+		const int wv = wvs;
+		int lanes = tid0 & 63;
+		asm volatile("" : "+v"(lanes));   // (opaque per step, as tidc below)
+		constexpr int IPT = NG / NWAVES;
+		cb_u32 keyrank[IPT];
 #pragma unroll
-	for (int k = 0; k < IPT; ++k) {
-		const int i = tid + k * NTHREADS;
-		keyrank[k] = 0;
-		if (i < NI) {
+		for (int k = 0; k < IPT; ++k) {
+			const int gi = wv + k * NWAVES, i = gi * 64 + lanes;
 			const int c = i % TW, g = i / TW;
 			int s0[4], e0[4], top, bot;
-			item_rows(c, g, s0, e0, top, bot);
-			const int ext = bot >= top ? bot - top + 1 : 0;
-			const cb_u32 rank = atomicAdd(&HISTl[ext], 1u);
-			keyrank[k] = (cb_u32)ext | (rank << 8);
-		}
-	}
-	__syncthreads();
-	if (tid < 64) {   // first position of every height, tallest first
-		cb_u32 below = 0;
-		for (int k = NKEY - 1; k > tid; --k) below += HISTl[k];
-		if (tid < NKEY) BASEl[tid] = below;
-	}
-	__syncthreads();
+			const cb_u32 udall = item_rows(c, g, s0, e0, top, bot);
+			int key = bot >= top ? bot - top + 2 : 0;
+			if (udall == 0x11111111u) {   // all four outputs reach one row up and down: 3 x 3 each if the six rows' runs are (1, 1)
+				bool mini = true;
+				int slot = base + A + 4 * g - 1;
+				slot = slot >= RR ? slot - RR : slot;
 #pragma unroll
-	for (int k = 0; k < IPT; ++k) {
-		const int i = tid + k * NTHREADS;
-		if (i < NI) {
+				for (int r = 0; r < 6; ++r) {
+					mini = mini && Ml[slot * TW + c] == 0x0304u;
+					slot = slot + 1 == RR ? 0 : slot + 1;
+				}
+				key = mini ? 1 : key;
+			}
+			cb_u32 rank = 0;
+			unsigned long long rem = ~0ull;
+			while (rem) {   // one pass per distinct key of the group
+				const int leader = __builtin_ctzll(rem);
+				const int k0 = __builtin_amdgcn_readlane(key, leader);
+				const unsigned long long m = __ballot(key == k0);
+				if (key == k0) rank = __builtin_amdgcn_mbcnt_hi((cb_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)m, 0));
+				if (lane == leader) GHl[gi * NKEY + k0] = (cb_u32)__builtin_popcountll(m);
+				rem &= ~m;
+			}
+			keyrank[k] = (cb_u32)key | (rank << 8);
+			// outputs without a partner are copied through (adcensus.cu:353-354); pixels outside the image never leave the tile
+			int oslot = base + A + 4 * g;
+#pragma unroll
+			for (int j = 0; j < 4; ++j, ++oslot) {
+				oslot = oslot >= RR ? oslot - RR : oslot;
+				if (((udall >> (8 * j)) & 0xffu) == 0xffu) OUTl[(4 * g + j) * TW + c] = Vl[oslot * SW + c + AH];
+			}
+		}
+		TPROF(2);
+		__syncthreads();
+		TPROF(3);
+		// counts -> positions, in every wave for itself (no second barrier): lane l owns key l.  Keys descending, inside a key
+		// group after group.
+		cb_u32 posbase[IPT];
+		int nz, nfast;
+		{
+			cb_u32 total = 0, pre[IPT];
+#pragma unroll
+			for (int k = 0; k < IPT; ++k) pre[k] = 0;
+#pragma unroll
+			for (int gi = 0; gi < NG; ++gi) {
+				const cb_u32 n = lane < NKEY ? GHl[gi * NKEY + lane] : 0u;
+#pragma unroll
+				for (int k = 0; k < IPT; ++k) pre[k] = gi == wv + k * NWAVES ? total : pre[k];
+				total += n;
+			}
+			// inclusive scan over the keys (lanes 0 .. 31): DPP row shifts, then row 0's sum into row 1
+			cb_u32 sc = total;
+			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xF, 0xF, false);   // row_shr:1
+			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xF, 0xF, false);   // row_shr:2
+			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xF, 0xF, false);   // row_shr:4
+			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x118, 0xF, 0xF, false);   // row_shr:8
+			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, DPP_ROW_BCAST15, 0xA, 0xF, false);
+			const cb_u32 all = (cb_u32)__builtin_amdgcn_readlane((int)sc, NKEY - 1);
+			const cb_u32 above = all - sc;   // items of larger keys
+			nz = NI - __builtin_amdgcn_readlane((int)total, 0);           // items with at least one output to compute
+			nfast = nz - __builtin_amdgcn_readlane((int)total, 1);        // ... of which the last ones are four 3 x 3 supports each
+#pragma unroll
+			for (int k = 0; k < IPT; ++k) posbase[k] = above + pre[k];
+		}
+#pragma unroll
+		for (int k = 0; k < IPT; ++k) {
+			const int gi = wv + k * NWAVES, i = gi * 64 + lanes;
 			const int c = i % TW, g = i / TW;
 			const cb_u32 key = keyrank[k] & 0xffu, rank = keyrank[k] >> 8;
-			TABl[BASEl[key] + rank] = (unsigned short)(c | (g << 8));
+			const cb_u32 first = (cb_u32)__builtin_amdgcn_ds_bpermute((int)(key * 4u), (int)posbase[k]);
+			TABl[first + rank] = (unsigned short)(c | (g << 8));
 		}
-	}
-	__syncthreads();
-	const int nz = NI - (int)HISTl[0];          // items with at least one output to compute
-	const int nchunks = (nz + 63) >> 6;
+		TPROF(4);
+		__syncthreads();
+		TPROF(5);
+		const int nchunks = (nz + 63) >> 6;
 
-	// ---- chunks of 64 items, tallest first --------------------------------------------------------------------------
-	for (;;) {
-		int chunk = 0;
-		if (lane == 0) chunk = (int)atomicAdd(&CTRl[0], 1u);
-		chunk = __builtin_amdgcn_readfirstlane(chunk);
-		if (chunk >= nchunks) break;
-		const int idx = chunk * 64 + lane;
-		const bool has = idx < nz;
-		const cb_u32 ent = TABl[has ? idx : 0];
-		const int c = (int)(ent & 0xffu), g = (int)(ent >> 8);
-		int s0[4], e0[4], top, bot;
-		item_rows(c, g, s0, e0, top, bot);
-		const int ext = has ? bot - top + 1 : 0;
-		const int E = __builtin_amdgcn_readfirstlane(ext);   // lane 0 holds the chunk's tallest item
-		int srel[4], erel[4];
+		// ---- chunks of 64 items, tallest first ----------------------------------------------------------------------
+		for (;;) {
+			int chunk = 0;
+			if (lane == 0) chunk = (int)atomicAdd(&CTRl[0], 1u);
+			chunk = __builtin_amdgcn_readfirstlane(chunk);
+			if (chunk >= nchunks) break;
+			const int idx = chunk * 64 + lane;
+			const bool has = idx < nz;
+			const cb_u32 ent = TABl[has ? idx : 0];
+			const int c = (int)(ent & 0xffu), g = (int)(ent >> 8);
+			if (chunk * 64 >= nfast) {
+				// every item of the chunk is four 3 x 3 supports: six rows x three values, nine additions per output in the
+				// reference's order, no lengths to look at
+				int slot = base + A + 4 * g - 1;
+				slot = slot >= RR ? slot - RR : slot;
+				float fs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			srel[j] = has ? s0[j] - top : 1 << 20;
-			erel[j] = has ? e0[j] - top : -1;
-		}
-		float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-		int cb[4] = {0, 0, 0, 0}, cnt[4] = {1, 1, 1, 1};
-		int Pn = 0;
-		int rowoff = top * SW + c + AH, mrow = top * TW + c;
-		for (int i = 0; i < E; ++i, rowoff += SW, mrow += TW) {
-			const bool act = i < ext;
-			const cb_u32 m = act ? (cb_u32)Ml[mrow] : 0u;
-			const int n = (int)(m >> 8);
-			const float *__restrict__ p = (const float *)((const char *)(Vl + rowoff) - (m & 0xffu));
+				for (int r = 0; r < 6; ++r) {   // window row r is row r - j of output j: outputs max(0, r - 2) .. min(3, r)
+					const float *__restrict__ p = Vl + slot * SW + c + AH - 1;
+					const float v0 = p[0], v1 = p[1], v2 = p[2];
+					slot = slot + 1 == RR ? 0 : slot + 1;
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+						if (j <= r && r <= j + 2) { fs[j] += v0; fs[j] += v1; fs[j] += v2; }
+				}
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					if (has) OUTl[(4 * g + j) * TW + c] = fs[j] / 9.0f;
+				continue;
+			}
+			int s0[4], e0[4], top, bot;
+			item_rows(c, g, s0, e0, top, bot);
+			const int ext = has ? bot - top + 1 : 0;
+			// lane 0 holds the chunk's tallest item -- except that the 3 x 3 class (six rows) is sorted behind every other class
+			const int E = max(__builtin_amdgcn_readfirstlane(ext), chunk * 64 + 64 > nfast ? 6 : 0);
+			int srel[4], erel[4];
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
-				const bool st = i == srel[j];   // the output's first row: its chain starts from +0.0 here
-				sum[j] = st ? 0.0f : sum[j];
-				cb[j] = st ? Pn : cb[j];
+				srel[j] = has ? s0[j] - top : 1 << 20;
+				erel[j] = has ? e0[j] - top : -1;
 			}
-			if (A > 4 && __any(n > 9)) {
-				if (__any(n > 18)) tile_taps<27>(p, n, sum);
-				else if (__any(n > 13)) tile_taps<18>(p, n, sum);
-				else tile_taps<13>(p, n, sum);
-			} else if (__any(n > 5)) {
-				tile_taps<9>(p, n, sum);
-			} else if (__any(n > 3)) {
-				tile_taps<5>(p, n, sum);
-			} else {
-				tile_taps<3>(p, n, sum);
-			}
-			Pn += n;
+			float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+			int cb[4] = {0, 0, 0, 0}, cnt[4] = {1, 1, 1, 1};
+			int Pn = 0;
+			int slot = has ? base + top : 0;
+			slot = slot >= RR ? slot - RR : slot;
+			cb_u32 evmask = 0;   // rows (relative to the item's top) at which one of its outputs starts or ends
 #pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const bool en = i == erel[j];   // the output's last row
-				res[j] = en ? sum[j] : res[j];
-				cnt[j] = en ? Pn - cb[j] : cnt[j];
+			for (int j = 0; j < 4; ++j)
+				if (erel[j] >= 0) evmask |= (1u << srel[j]) | (1u << erel[j]);
+			cb_u32 mnext = ext > 0 ? (cb_u32)Ml[slot * TW + c] : 0u;
+			for (int i = 0; i < E; ++i) {
+				const cb_u32 m = mnext;
+				const int n = (int)(m >> 8);
+				const float *p = (const float *)((const char *)(Vl + slot * SW + c + AH) - (m & 0xffu));
+				slot = slot + 1 == RR ? 0 : slot + 1;
+				const cb_u32 mr = Ml[slot * TW + c];   // the next row's run travels while this row is summed
+				mnext = i + 1 < ext ? mr : 0u;
+				const bool anyev = __any((evmask >> i) & 1u);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
+				if (anyev) {
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						const bool st = i == srel[j];   // the output's first row: its chain starts from +0.0 here
+						sum[j] = st ? 0.0f : sum[j];
+						cb[j] = st ? Pn : cb[j];
+					}
+				}
+				tile_taps<(A > 4)>(p, n, sum);
+				Pn += n;
+				if (anyev) {
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						const bool en = i == erel[j];   // the output's last row
+						res[j] = en ? sum[j] : res[j];
+						cnt[j] = en ? Pn - cb[j] : cnt[j];
+					}
+				}
 			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+				if (erel[j] >= 0) OUTl[(4 * g + j) * TW + c] = res[j] / (float)cnt[j];
 		}
-#pragma unroll
-		for (int j = 0; j < 4; ++j)
-			if (erel[j] >= 0) OUTl[(4 * g + j) * TW + c] = res[j] / (float)cnt[j];
-	}
-	__syncthreads();
+		TPROF(6);
+		__syncthreads();
+		TPROF(7);
 
-	// ---- results leave as rows ---------------------------------------------------------------------------------------
-	constexpr int OPR = TW / 4;
-	for (int q = tid; q < TH * OPR; q += NTHREADS) {
-		const int r = q / OPR, u = q - r * OPR;
-		const int y = ty0 + r, x = tx0 + 4 * u;
-		if (y >= H || x >= W) continue;
-		const cb_f4 o = *(const cb_f4 *)(OUTl + r * TW + 4 * u);
-		const int ob = y * W + x;
-		if (x + 3 < W) {
-			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)}, ro,
-			                                       (cb_u32)ob * 4u, 0, VOL_AUX);
-		} else {
-			const float oo[4] = {o.x, o.y, o.z, o.w};
+		// ---- the rows the next step adds replace the oldest ones; results leave as rows; the rows of the step after next are
+		// requested.  Order matters on gfx9, where stores and loads share one in-order counter: the committed rows were
+		// requested a whole step ago and are waited for BEFORE this step's stores are issued, and the stored values keep their
+		// registers until the new loads are out -- so nothing here waits for a store to complete.
+		int tidc = tid0;
+		asm volatile("" : "+v"(tidc));   // (opaque: the per-thread index arithmetic of commit / fetch is redone per step instead of living in ~40 registers)
+		if (more) commit_rows(R, rrn, base, TH, tidc);   // relative row rrn = RR + k TH lives in slot (k TH) mod RR = base: the oldest rows go
+		TPROF(8);
+		// a wave stores whole rows through a descriptor that ends with the row: the words of a last unit that lie beyond the
+		// image (W not a multiple of 4) are dropped by the range check, rows beyond the region get an empty descriptor -- no branch
+		constexpr int OPR = TW / 4;
+		constexpr int NO = TH / NWAVES;
+		static_assert(OPR <= 64 && TH % NWAVES == 0, "a wave stores whole rows");
+		cb_f4 ov[NO];
 #pragma unroll
-			for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oo[k]), ro, x + k < W ? (cb_u32)(ob + k) * 4u : OOB, 0, 0);
+		for (int k = 0; k < NO; ++k) {
+			const int r = wvs * NO + k;
+			const int y = y0 + r;
+			const int x = tx0 + 4 * lane;
+			const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(P.vout + (size_t)d * HWi), 0, y < ye ? (y + 1) * W * 4 : 0, 0x00020000);
+			ov[k] = *(const cb_f4 *)(OUTl + r * TW + 4 * (lane < OPR ? lane : 0));
+			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(ov[k].x), __float_as_uint(ov[k].y), __float_as_uint(ov[k].z), __float_as_uint(ov[k].w)}, rrow,
+			                                       lane < OPR ? (cb_u32)(y * W + x) * 4u : OOB, 0, VOL_AUX);
 		}
+		for (int q = tid; q < NG * NKEY; q += NTHREADS) GHl[q] = 0;
+		if (tid == 0) CTRl[0] = 0;
+		if (y0 + 2 * TH < ye) fetch_rows(R, rrn + TH, TH, tidc);
+#pragma unroll
+		for (int k = 0; k < NO; ++k) asm volatile("" :: "v"(ov[k]));   // (the stored values keep their registers until here)
+		base += TH;
+		base = base >= RR ? base - RR : base;
+		TPROF(9);
+		__syncthreads();
+		TPROF(10);
+#ifdef MC_TILE_PROF
+		++step_no;
+#endif
 	}
 }
 
+#ifdef MC_TILE_PROF
+extern "C" __attribute__((visibility("default"))) int mc_debug_tile_prof(unsigned long long *out, int n)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tile_prof), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+
 template <int A, int TW, int TH, int NWAVES>
-static int cbca_tiles_launch(const CbcaArgs &P, bool nt, int gate, hipStream_t st)
+static int cbca_tiles_launch(CbcaArgs P, bool nt, hipStream_t st)
 {
 	using G = TileGeo<A, TW, TH>;
-	const int tiles_x = (int)cdiv(P.W, TW), tiles_y = (int)cdiv(P.H, TH);
-	const int tpp = tiles_x * tiles_y;
-	const int64_t blocks = (int64_t)cdiv(P.nd, 8) * 8 * tpp;
+	// regions: strips of TW columns x row ranges of a multiple of TH rows; enough of them for ~5 regions per XCD, a multiple
+	// of 8 where a nearby row split gives one
+	P.gx = (int)cdiv(P.W, TW);
+	const int steps = (int)cdiv(P.H, TH);
+	int gy = std::max(1, std::min(steps, (int)cdiv(40, P.gx)));
+	for (int t = gy; t < gy + 8 && t <= steps; ++t)
+		if ((P.gx * t) % 8 == 0) { gy = t; break; }
+	P.rb = (int)cdiv(steps, gy) * TH;
+	P.gy = (int)cdiv(P.H, P.rb);
+	const int64_t blocks = (int64_t)cdiv((int64_t)P.gx * P.gy, 8) * 8 * P.nd;
 	if (blocks > 0x7fffffff) {
 		set_error("cbca_tiles: %lld blocks", (long long)blocks);
 		return MC_EINVAL;
@@ -352,14 +505,14 @@ static int cbca_tiles_launch(const CbcaArgs &P, bool nt, int gate, hipStream_t s
 		(void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
 		attr_done = true;
 	}
-	if (nt) hipLaunchKernelGGL(kern_nt, dim3((unsigned)blocks), dim3(64 * NWAVES), G::LDS_BYTES, st, P, tiles_x, tpp, gate);
-	else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWAVES), G::LDS_BYTES, st, P, tiles_x, tpp, gate);
+	if (nt) hipLaunchKernelGGL(kern_nt, dim3((unsigned)blocks), dim3(64 * NWAVES), G::LDS_BYTES, st, P);
+	else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWAVES), G::LDS_BYTES, st, P);
 	return check_launch("cbca_tile");
 }
 
-// arm_class 4: every arm <= 4 (L1 <= 5); 13: every arm <= 13 (L1 <= 14).  gate != 0 (arm bound unknown to the caller): the
-// launch stands down unless cbca_pack's flags say its arm class holds (bits: see the kernel).
-int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int gate,
+// arm_class 4: every arm <= 4 (L1 <= 5); 13: every arm <= 13 (L1 <= 14).  route >= 0 (the caller does not know the arms): the
+// launch stands down unless cbca_pack's route word equals it.
+int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int route,
                hipStream_t st, const CbcaCfg &cfg)
 {
 	const int d0 = cfg.nd > 0 ? cfg.d0 : 0, nd = cfg.nd > 0 ? cfg.nd : D;
@@ -369,23 +522,23 @@ int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, 
 	P.vin = vin; P.vout = vout;
 	P.D = D; P.H = H; P.W = W; P.direction = direction;
 	P.d0 = d0; P.nd = nd;
-	P.rb = 0; P.by_arm = 0; P.gx = P.gy = 0;
-	P.overflow = gate ? cs.flag : nullptr;
+	P.rb = 0; P.gx = P.gy = 0;   // (regions: set by the launcher)
+	P.flags = route >= 0 ? cs.flag : nullptr;
+	P.route = route;
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
-	// cfg.rb selects the tile geometry (test / tuning hook; 0 = the product's choice)
+	// cfg.variant selects the tile geometry (test / tuning hook; 0 = the product's choice)
 	if (arm_class <= 4) {
-		switch (cfg.rb) {
-		case 1: return cbca_tiles_launch<4, 128, 32, 8>(P, nt, gate, st);
-		case 2: return cbca_tiles_launch<4, 128, 32, 4>(P, nt, gate, st);
-		case 3: return cbca_tiles_launch<4, 256, 16, 8>(P, nt, gate, st);
-		default: return cbca_tiles_launch<4, 128, 16, 4>(P, nt, gate, st);
+		switch (cfg.variant) {
+		case 1: return cbca_tiles_launch<4, 128, 32, 8>(P, nt, st);
+		case 2: return cbca_tiles_launch<4, 128, 32, 4>(P, nt, st);
+		case 3: return cbca_tiles_launch<4, 256, 16, 8>(P, nt, st);
+		default: return cbca_tiles_launch<4, 128, 16, 4>(P, nt, st);
 		}
 	}
-	switch (cfg.rb) {
-	case 1: return cbca_tiles_launch<13, 128, 32, 8>(P, nt, gate, st);
-	case 2: return cbca_tiles_launch<13, 128, 32, 4>(P, nt, gate, st);
-	case 3: return cbca_tiles_launch<13, 128, 16, 8>(P, nt, gate, st);
-	default: return cbca_tiles_launch<13, 128, 16, 4>(P, nt, gate, st);
+	switch (cfg.variant) {
+	case 1: return cbca_tiles_launch<13, 128, 32, 8>(P, nt, st);
+	case 2: return cbca_tiles_launch<13, 128, 16, 4>(P, nt, st);
+	default: return cbca_tiles_launch<13, 128, 16, 8>(P, nt, st);
 	}
 }
 

@@ -25,13 +25,12 @@ int check_launch(const char *what);  // hipPeekAtLastError -> rc, like checkCuda
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
-// launch configuration of the cbca strip kernels; the defaults derive everything from the problem size
+// launch configuration of the cbca strip / tile kernels; the defaults derive everything from the problem size
 struct CbcaCfg {
 	int rb = 0;        // output rows per strip (0 = auto)
 	int nt = -1;       // volume cache policy: -1 auto, 0 default, 1 non-temporal
 	int d0 = 0, nd = 0;// planes [d0, d0 + nd) only (nd = 0: all)
-	int form = 0;      // kernel: 0 auto (by the largest possible arm), 1 strip kernel, 2 window kernel (arms <= 4 only)
-	                   // (the hook's form 3 = strip kernel + the pair's list, is not a cfg value)
+	int variant = 0;   // tile kernel: geometry variant (0 = the product's choice)
 };
 
 // ---- wave64 cross-lane primitives (DPP, no LDS round trip) -------------------

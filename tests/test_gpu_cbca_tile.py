@@ -1,4 +1,4 @@
-"""-m gpu: the LDS-tile kernel of cross-based aggregation (cbca forms 4 / 5 of the hook: short-arm instance, arms <= 4, and
+"""-m gpu: the LDS-tile kernel of cross-based aggregation (cbca forms 2 / 3 of the hook: short-arm instance, arms <= 4, and
 long-arm instance, arms <= 13 -- what mc_predict runs for L1 <= 5 / L1 <= 14) against the oracle, bit for bit: every kind of
 arm statistics, tiles with ragged edges (H, W not multiples of the tile), images smaller than one tile, both directions, both
 cache policies, plane sub-ranges, special values inside the valid region."""
@@ -34,7 +34,7 @@ def test_tile_kernel_short_arms(mc, oracle, H, W, D, mk, L1, tau1):
     for direction, vol in ((-1, vl), (1, vr)):
         want = oracle.cbca(x0c, x1c, vol, direction)
         out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, nt=(H + W) & 1, form=4)
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, nt=(H + W) & 1, form=2)
         got = out.cpu().numpy()
         assert same_bits(got, want), diff_report(got, want, "tile kernel (arms <= 4) dir=%d" % direction)
 
@@ -50,12 +50,12 @@ def test_tile_kernel_long_arms(mc, oracle, H, W, D, mk, L1, tau1):
     for direction, vol in ((-1, vl), (1, vr)):
         want = oracle.cbca(x0c, x1c, vol, direction)
         out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, nt=(H + W) & 1, form=5)
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, nt=(H + W) & 1, form=3)
         got = out.cpu().numpy()
         assert same_bits(got, want), diff_report(got, want, "tile kernel (arms <= 13) dir=%d" % direction)
 
 
-@pytest.mark.parametrize("form,L1", [(4, 5), (5, 14)])
+@pytest.mark.parametrize("form,L1", [(2, 5), (3, 14)])
 def test_tile_kernel_plane_range(mc, oracle, form, L1):
     H, W, D = 30, 200, 21
     x0, x1 = blocky_pair(H, W, seed=4)
@@ -69,7 +69,7 @@ def test_tile_kernel_plane_range(mc, oracle, form, L1):
     assert (got[:3] == -7.0).all() and (got[16:] == -7.0).all(), "planes outside [d0, d0+nd) were written"
 
 
-@pytest.mark.parametrize("form,L1", [(4, 5), (5, 14)])
+@pytest.mark.parametrize("form,L1", [(2, 5), (3, 14)])
 def test_tile_kernel_special_values(mc, oracle, form, L1):
     """zeros, negative zeros, denormals, huge values, infinities and NaNs inside the valid region: a value that is not in a
     support is never an operand of its chain -- neither a neighbour's tap nor what an accumulator collected before its
@@ -97,12 +97,12 @@ def test_tile_kernel_special_values(mc, oracle, form, L1):
 
 
 def test_tile_kernel_stands_down_when_an_arm_is_too_long(mc, oracle):
-    """the hook's forms 4 / 5 write nothing if cbca_pack saw an arm beyond the instance's class"""
+    """the hook's forms 2 / 3 write nothing if cbca_pack saw an arm beyond the instance's class"""
     H, W, D = 40, 100, 3
     x0 = np.zeros((H, W), np.float32)
     x0c = oracle.cross(x0, 20, 1.0)
     vl, _ = raw_volumes(D, H, W, seed=3)
-    for form in (4, 5):
+    for form in (2, 3):
         out = torch.full((1, D, H, W), -7.0, device="cuda")
         mc.adcensus.cbca_cfg(dev(x0c), dev(x0c), dev(vl), out, -1, form=form)
         assert (out.cpu().numpy() == -7.0).all()

@@ -1,7 +1,8 @@
 """-m gpu: the kernel instantiations that only the benchmarked SIZES select, forced at small shapes through the
 test hooks of the C ABI (mc_cbca_ws_cfg, mc_transpose_cfg) and compared with the oracle:
 
-  * rows per CBCA strip rb in {16, 25, 40} (KITTI size runs 25, 1000x1500 runs 40; small shapes pick 16),
+  * rows per CBCA strip rb in {16, 25, 40} of the strip kernel (KITTI size runs 25, 1000x1500 runs 40; small shapes pick 16),
+  * the route adcensus.cbca takes by the pair's arms (tile kernel short / long arms, strip kernel, one thread per voxel),
   * the non-temporal instantiations of the CBCA strip kernel and of the layout transposes (selected above 768 MB),
   * plane sub-ranges of a volume.
 (tests/test_gpu_fullsize.py checks the same code at the real sizes against the reference's kernels.)"""
@@ -30,7 +31,7 @@ def test_cbca_forced_rows_and_cache_policy(mc, oracle, H, W, D, rb, nt, mk, L1, 
     for direction, vol in ((-1, vl), (1, vr)):
         want = oracle.cbca(x0c, x1c, vol, direction)
         out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=nt)
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=nt, form=1)
         got = out.cpu().numpy()
         assert same_bits(got, want), diff_report(got, want, "cbca rb=%d nt=%d dir=%d" % (rb, nt, direction))
 
@@ -102,113 +103,49 @@ def test_cbca_special_values(mc, oracle):
         want = oracle.cbca(x0c, x1c, vl, -1)
     for rb, nt in ((0, -1), (25, 1)):
         out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=rb, nt=nt)
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=rb, nt=nt, form=1)
         got = out.cpu().numpy()
         assert same_bits(got, want), diff_report(got, want, "special values rb=%d nt=%d" % (rb, nt))
 
 
-# ---- the window kernel (cbca form 2: what mc_predict takes for L1 <= 5) ---------------------------------------------
-@pytest.mark.parametrize("H,W,D", [(90, 300, 9), (41, 519, 6), (27, 253, 5), (83, 64, 12), (37, 249, 4), (12, 497, 3)])
-@pytest.mark.parametrize("rb", [0, 16, 40])
-@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 5, 0.13), ("random", 5, 0.5), ("blocky", 5, 0.2), ("natural", 5, 0.13),
-                                        ("natural", 3, 0.03), ("blocky", 2, 0.3), ("smooth", 0, 0.0), ("natural", 4, 1.0)])
-def test_cbca_window_kernel(mc, oracle, H, W, D, rb, mk, L1, tau1):
-    """short arms (<= 4): every kind of image, strips with ragged edges, all row-chunk sizes, both cache policies, both
-    directions -- against the oracle, bit for bit"""
+# ---- adcensus.cbca's routes: the kernel the pair's arms call for is picked on the device (cbca_pack's route word) -------
+@pytest.mark.parametrize("mk,L1,tau1,what", [
+    ("smooth", 14, 0.02, "textured pair, nearly every support 3x3: strip kernel"),
+    ("natural", 14, 0.02, "real-scene statistics, arms <= 13: tile kernel, long-arm instance"),
+    ("natural", 5, 0.13, "arms <= 4: tile kernel, short-arm instance"),
+    ("blocky", 34, 10.0, "arms as long as the image allows: strip kernel"),
+    ("flat", 400, 1.0, "an arm longer than 254 pixels: one thread per voxel"),
+])
+@pytest.mark.parametrize("H,W,D", [(60, 300, 7), (37, 449, 4)])
+def test_cbca_routes(mc, oracle, mk, L1, tau1, what, H, W, D):
     from util import natural_pair
-    x0, x1 = {"smooth": lambda: smooth_pair(H, W, 8, seed=H), "random": lambda: random_pair(H, W, seed=W),
-              "blocky": lambda: blocky_pair(H, W, seed=D), "natural": lambda: natural_pair(H, W, 8, seed=H + W, sigma=8.0)}[mk]()
+    x0, x1 = {"smooth": lambda: smooth_pair(H, W, 8, seed=H), "blocky": lambda: blocky_pair(H, W, seed=D),
+              "natural": lambda: natural_pair(H, W, 8, seed=H + W, sigma=8.0),
+              "flat": lambda: (np.zeros((H, W), np.float32), np.zeros((H, W), np.float32))}[mk]()
     x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
     vl, vr = raw_volumes(D, H, W, seed=13)
     for direction, vol in ((-1, vl), (1, vr)):
         want = oracle.cbca(x0c, x1c, vol, direction)
         out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=(H + rb) & 1, form=2)
+        mc.adcensus.cbca(dev(x0c), dev(x1c), dev(vol), out, direction)
         got = out.cpu().numpy()
-        assert same_bits(got, want), diff_report(got, want, "window kernel rb=%d dir=%d" % (rb, direction))
-
-
-def test_cbca_window_kernel_special_values(mc, oracle):
-    """zeros, negative zeros, denormals, huge values, infinities and NaNs inside the valid region: a tap that is not in the
-    support is never an operand (an inf / NaN next to a support must not leak into it), a support of nothing but -0.0
-    sums to +0.0"""
-    H, W, D = 40, 260, 6
-    x0, x1 = blocky_pair(H, W, seed=8)
-    x0c, x1c = oracle.cross(x0, 5, 0.2), oracle.cross(x1, 5, 0.2)
-    vl, _ = raw_volumes(D, H, W, seed=3)
-    rng = np.random.default_rng(1)
-    vl[0, :, 20:] = 0.0
-    vl[1, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-42)
-    vl[2, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-30)
-    vl[3, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(3e38)
-    for k in range(40):
-        vl[4, rng.integers(0, H), rng.integers(20, W)] = np.inf if k & 1 else np.nan
-    vl[5, :, 20:] = -rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-38)
-    vl[5, 25:, 20:] = -0.0
-    with np.errstate(all="ignore"):
-        want = oracle.cbca(x0c, x1c, vl, -1)
-    for rb, nt in ((0, -1), (25, 1)):
-        out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=rb, nt=nt, form=2)
-        got = out.cpu().numpy()
-        assert same_bits(got, want), diff_report(got, want, "window kernel special values rb=%d nt=%d" % (rb, nt))
+        assert same_bits(got, want), diff_report(got, want, "adcensus.cbca (%s) dir=%d" % (what, direction))
 
 
 def test_cbca_forms_agree_on_a_realistic_pair(mc):
-    """strip kernel, window kernel and the one-thread-per-voxel kernel on a pair with real-scene arm statistics"""
+    """strip kernel, both tile instances, adcensus.cbca's own choice and the one-thread-per-voxel kernel on a pair with
+    real-scene arm statistics"""
     from util import natural_pair
     H, W, D = 120, 700, 20
     x0, x1 = natural_pair(H, W, D, seed=5)
     xb = dev(np.stack([x0, x1]))[:, None]
-    x0c = torch.empty((1, 4, H, W), device="cuda"); x1c = torch.empty_like(x0c)
-    mc.adcensus.cross(xb[0:1], x0c, 5, 0.13); mc.adcensus.cross(xb[1:2], x1c, 5, 0.13)
-    vin = torch.rand((1, D, H, W), device="cuda")
-    outs = []
-    for form in (1, 2):
-        o = torch.full_like(vin, -7.0)
-        mc.adcensus.cbca_cfg(x0c, x1c, vin, o, -1, form=form)
-        outs.append(o.cpu().numpy())
-    o = torch.full_like(vin, -7.0)
-    mc.adcensus.cbca_reference_shaped(x0c, x1c, vin, o, -1)
-    assert same_bits(outs[0], o.cpu().numpy()) and same_bits(outs[1], o.cpu().numpy())
-
-
-# ---- strip kernel + the pair's list of large supports (cbca form 3: what mc_predict takes for L1 > 5) -----------------
-@pytest.mark.parametrize("H,W,D", [(90, 300, 9), (41, 519, 6), (60, 253, 5), (83, 64, 12), (37, 449, 4), (140, 230, 3)])
-@pytest.mark.parametrize("rb", [0, 25])
-@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.02), ("natural", 14, 0.02), ("blocky", 14, 0.2), ("natural", 9, 0.05),
-                                        ("blocky", 6, 0.3), ("natural", 5, 0.13), ("random", 14, 2.5), ("blocky", 34, 10.0)])
-def test_cbca_listed(mc, oracle, H, W, D, rb, mk, L1, tau1):
-    """supports that do not fit the strip kernel's window form come from the list kernel: every kind of arm statistics, up
-    to arms as long as the image allows (("blocky", 34, 10.0)), both directions, both cache policies"""
-    from util import natural_pair
-    x0, x1 = {"smooth": lambda: smooth_pair(H, W, 8, seed=H), "random": lambda: random_pair(H, W, seed=W),
-              "blocky": lambda: blocky_pair(H, W, seed=D), "natural": lambda: natural_pair(H, W, 8, seed=H + W, sigma=8.0)}[mk]()
-    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
-    vl, vr = raw_volumes(D, H, W, seed=13)
-    for direction, vol in ((-1, vl), (1, vr)):
-        want = oracle.cbca(x0c, x1c, vol, direction)
-        out = torch.full((1, D, H, W), -7.0, device="cuda")
-        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, nt=(H + rb) & 1, form=3)
-        got = out.cpu().numpy()
-        assert same_bits(got, want), diff_report(got, want, "listed rb=%d dir=%d" % (rb, direction))
-
-
-def test_cbca_listed_special_values(mc, oracle):
-    H, W, D = 40, 260, 6
-    x0, x1 = blocky_pair(H, W, seed=8)
-    x0c, x1c = oracle.cross(x0, 14, 0.2), oracle.cross(x1, 14, 0.2)
-    vl, _ = raw_volumes(D, H, W, seed=3)
-    rng = np.random.default_rng(1)
-    vl[0, :, 20:] = 0.0
-    vl[1, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(1e-42)
-    vl[3, :, 20:] = rng.random((H, W - 20)).astype(np.float32) * np.float32(3e38)
-    for k in range(40):
-        vl[4, rng.integers(0, H), rng.integers(20, W)] = np.inf if k & 1 else np.nan
-    vl[5, 25:, 20:] = -0.0
-    with np.errstate(all="ignore"):
-        want = oracle.cbca(x0c, x1c, vl, -1)
-    out = torch.full((1, D, H, W), -7.0, device="cuda")
-    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, form=3)
-    got = out.cpu().numpy()
-    assert same_bits(got, want), diff_report(got, want, "listed, special values")
+    for L1, tau1, forms in ((5, 0.13, (0, 1, 2, 3)), (14, 0.02, (0, 1, 3))):
+        x0c = torch.empty((1, 4, H, W), device="cuda"); x1c = torch.empty_like(x0c)
+        mc.adcensus.cross(xb[0:1], x0c, L1, tau1); mc.adcensus.cross(xb[1:2], x1c, L1, tau1)
+        vin = torch.rand((1, D, H, W), device="cuda")
+        ref = torch.full_like(vin, -7.0)
+        mc.adcensus.cbca_reference_shaped(x0c, x1c, vin, ref, -1)
+        for form in forms:
+            o = torch.full_like(vin, -7.0)
+            mc.adcensus.cbca_cfg(x0c, x1c, vin, o, -1, form=form)
+            assert same_bits(o.cpu().numpy(), ref.cpu().numpy()), "L1=%d form %d" % (L1, form)
