@@ -77,12 +77,14 @@ def pick_dominant(stage_ms, ab):
     return max(cands, key=lambda k: stage_ms[k]) if cands else None
 
 
-# image pair per config: the KITTI shapes are specified on the reference's real sample pair, which does not
-# travel to the GPU box -- tests/util.natural_pair reproduces its cross-arm statistics (calibration in its docstring); the
-# 1000x1500 case is specified as a Gaussian texture (sigma 3 px), tests/util.smooth_pair.  CBCA is the one stage whose
-# cost depends on the pair: its additions per voxel are the support sizes (9 on a texture, ~40 on real scenes).
-PAIR_OF = {"kitti_fast": "natural", "kitti_slow": "natural", "kitti_slow_fc": "natural", "mb_slow": "texture", "tiny": "texture"}
-PAIR_NOTE = {"natural": "synthetic pair with the cross-arm statistics of the reference's real KITTI sample pair (tests/util.natural_pair)",
+# image pair per config: the KITTI shapes are specified on the reference's real sample pair (a committed
+# fixture, tests/util.sample_pair); the 1000x1500 case is specified as a Gaussian texture (sigma 3 px), tests/util.smooth_pair,
+# and gets two realistic sub-records: tests/util.natural_pair (synthetic, calibrated against the sample pair by
+# tests/test_inputs.py) and the sample pair mirror-tiled to 1000x1500.  CBCA is the one stage whose cost depends on the
+# pair: its additions per voxel are the support sizes (9 on a texture, ~40 on real scenes).
+PAIR_OF = {"kitti_fast": "sample", "kitti_slow": "sample", "kitti_slow_fc": "sample", "mb_slow": "texture", "tiny": "texture"}
+PAIR_NOTE = {"sample": "the reference's real sample pair samples/input/kittiL.png / kittiR.png (tests/golden/kitti_sample_pair.npz; mirror-tiled where the shape is not 370x1226)",
+             "natural": "synthetic pair with the cross-arm statistics of the reference's real KITTI sample pair (tests/util.natural_pair)",
              "texture": "Gaussian texture, sigma 3 px, shifted by a smooth disparity field (SURVEY 8(d) recipe, tests/util.smooth_pair)"}
 
 
@@ -92,10 +94,13 @@ def config_key(cfg):
 
 def make_inputs(cfg, rank, device, pair=None):
     import torch
-    from util import features, natural_pair, raw_volumes, smooth_pair
+    from util import features, natural_pair, raw_volumes, sample_pair, smooth_pair
     preset, H, W, D, C, _ = cfg
     pair = pair or PAIR_OF[config_key(cfg)]
-    x0, x1 = (natural_pair if pair == "natural" else smooth_pair)(H, W, D, seed=1234 + rank)
+    if pair == "sample":   # (one real pair: every rank sees the same images; features / raw volumes are seeded per rank)
+        x0, x1 = sample_pair(H, W)
+    else:
+        x0, x1 = (natural_pair if pair == "natural" else smooth_pair)(H, W, D, seed=1234 + rank)
     xb = torch.from_numpy(np.stack([x0, x1])[:, None]).to(device)
     host = dict(x0=x0, x1=x1)
     if C < 0:  # accurate net: non-negative (post-ReLU) features + a seeded FC stack (no trained nets are available)
@@ -366,11 +371,12 @@ def north_star_record(device, steps=5):
     rec["per_volume"]["box_copy_GBs"] = round(cr, 1)
     rec["per_volume"]["sweep_over_box_copy"] = round(budget / (sweep_ms * 1e-3) / 1e9 / cr, 4)
     rec["pair"] = PAIR_NOTE["texture"]
-    rec["realistic_pair"] = north_star_realistic(device)
+    rec["realistic_pair"] = north_star_realistic(device, "natural")
+    rec["realistic_pair_sample"] = north_star_realistic(device, "sample")
     return rec
 
 
-def north_star_realistic(device):
+def north_star_realistic(device, pair):
     """The same sweep on a pair with real-scene arm statistics: cross-based aggregation does ~45 additions per voxel there
     (half of the supports minimal, 4-6 % flat regions of up to 27 x 27 taps) instead of 9 -- it is bound by the serial
     additions the reference's summation order imposes, not by HBM.  One pair, reference check included."""
@@ -380,7 +386,7 @@ def north_star_realistic(device):
     cfg = CONFIGS["mb_slow"]
     preset, H, W, D, C, name = cfg
     prm = dict(mc.PRESETS[preset])
-    xb, kw, _ = make_inputs(cfg, 0, device, pair="natural")
+    xb, kw, _ = make_inputs(cfg, 0, device, pair=pair)
     ws = Workspace(prm, D, H, W, device)
     out = torch.empty((1, 1, H, W), dtype=torch.float32, device=device)
 
@@ -405,10 +411,10 @@ def north_star_realistic(device):
     except Exception as e:
         ops_ms = "error: %s" % str(e)[:200]
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic_mb_slow_natural.json")
+    tfile = os.path.join(ROOT, "profiles", "traffic_mb_slow_%s.json" % pair)
     if os.path.exists(tfile):
         traffic = json.load(open(tfile)).get("cbca")
-    rec = dict(pair=PAIR_NOTE["natural"], ms_per_pair=round(sum(acc.values()), 2), stage_ms={k: round(v, 3) for k, v in acc.items()},
+    rec = dict(pair=PAIR_NOTE[pair], ms_per_pair=round(sum(acc.values()), 2), stage_ms={k: round(v, 3) for k, v in acc.items()},
                ops_ms_per_pair=ops_ms, cbca_traffic=traffic,
                cbca_ms_per_launch=round(acc.get("cbca", 0) / (2 * n_it), 3), cbca_additions_per_voxel=round(apv, 2),
                cbca_additions_T_per_s=round(adds / (acc["cbca"] * 1e-3) / 1e12, 3),
@@ -449,7 +455,7 @@ def main():
     ap.add_argument("--no-ref-gpu", action="store_true", help="skip the verify leg (reference's own kernels on this GPU)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 1000x1500x256 sub-record of the default run")
     ap.add_argument("--no-ops", action="store_true", help="skip timing the op-by-op (unchanged main.lua) route")
-    ap.add_argument("--pair", choices=("natural", "texture"), default=None,
+    ap.add_argument("--pair", choices=("sample", "natural", "texture"), default=None,
                     help="image pair (default per config, PAIR_OF): real-scene arm statistics or the Gaussian texture")
     args = ap.parse_args()
 

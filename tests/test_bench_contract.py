@@ -65,11 +65,11 @@ def test_gpus_n_without_a_launcher_spawns_its_own_ranks():
 
 
 def test_every_config_names_its_image_pair():
-    """the pair decides the cost of cbca: KITTI shapes on the realistic pair, 1000x1500 on the specified texture"""
+    """the pair decides the cost of cbca: KITTI shapes on the reference's real sample pair, 1000x1500 on the specified texture"""
     b = _bench() if "_bench" in globals() else __import__("bench")
     assert set(b.PAIR_OF) == set(b.CONFIGS)
     assert all(v in b.PAIR_NOTE for v in b.PAIR_OF.values())
-    assert b.PAIR_OF["kitti_fast"] == b.PAIR_OF["kitti_slow"] == "natural" and b.PAIR_OF["mb_slow"] == "texture"
+    assert b.PAIR_OF["kitti_fast"] == b.PAIR_OF["kitti_slow"] == "sample" and b.PAIR_OF["mb_slow"] == "texture"
     assert b.config_key(b.CONFIGS["kitti_slow_fc"]) == "kitti_slow_fc"
 
 

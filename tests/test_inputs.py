@@ -1,7 +1,7 @@
 """The synthetic image pairs of bench.py / the tests: their cross-arm statistics are what decides the cost of cbca."""
 import numpy as np
 
-from util import natural_pair, smooth_pair
+from util import natural_pair, sample_pair, smooth_pair
 
 
 def arm_lengths(oracle, x, L1, tau1):
@@ -36,3 +36,35 @@ def test_smooth_pair_is_the_textured_extreme(oracle):
     x0, x1 = smooth_pair(120, 400, 32, seed=3)
     a = np.minimum(arm_lengths(oracle, x0, 14, 0.02), arm_lengths(oracle, x1, 14, 0.02))
     assert non_minimal_share(a) < 0.1 and a.max() <= 13
+
+
+def arm_stats(oracle, x0, x1, L1, tau1, ds=(0, 30, 60, 120)):
+    """share of supports larger than 3x3 / share of per-arm minima at the L1 - 1 limit / mean arm, arms combined over both
+    images as cbca combines them (left pixel x with right pixel x - d)"""
+    a0, a1 = arm_lengths(oracle, x0, L1, tau1), arm_lengths(oracle, x1, L1, tau1)
+    W = x0.shape[1]
+    rows = []
+    for d in ds:
+        a = np.minimum(a0[:, :, d:], a1[:, :, :W - d] if d else a1)
+        rows.append((non_minimal_share(a), (a == L1 - 1).mean(), a.mean()))
+    return np.array(rows)
+
+
+def test_natural_pair_is_calibrated_against_the_reference_sample_pair(oracle):
+    """tests/util.natural_pair (the synthetic pair of the 1000x1500 realistic record and of most GPU tests) against the
+    reference's real pair under the three parameter sets its docstring quotes: the statistics that decide the cost of
+    cbca -- share of non-minimal supports, share of arms at the limit, mean arm -- agree within the stated bands"""
+    real = sample_pair()
+    syn = natural_pair(370, 1226, 228)
+    for (L1, tau1), tol in (((5, 0.13), (0.08, 0.15, 0.5)), ((14, 0.02), (0.12, 0.06, 0.8)), ((5, 0.03), (0.15, 0.12, 0.5))):
+        r, s_ = arm_stats(oracle, *real, L1, tau1), arm_stats(oracle, *syn, L1, tau1)
+        for k in range(3):
+            assert abs(r[:, k].mean() - s_[:, k].mean()) < tol[k], (L1, tau1, k, r[:, k], s_[:, k])
+
+
+def test_sample_pair_fixture():
+    x0, x1 = sample_pair()
+    assert x0.shape == x1.shape == (370, 1226) and x0.dtype == np.float32
+    assert abs(x0.mean()) < 1e-3 and abs(x0.std(ddof=1) - 1) < 1e-3
+    t0, t1 = sample_pair(1000, 1500)
+    assert t0.shape == (1000, 1500) and abs(t1.mean()) < 1e-3

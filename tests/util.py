@@ -59,6 +59,25 @@ def natural_pair(H, W, D, seed=1234, sigma=40.0, tex_frac=0.25, tex_amp=0.35, se
     return normalize_image(sensor(clean)[:, :W]), normalize_image(sensor(shifted)[:, :W])
 
 
+def sample_pair(H=None, W=None):
+    """The reference's one real input pair (samples/input/kittiL.png / kittiR.png, 370 x 1226, 8-bit grey; committed as
+    tests/golden/kitti_sample_pair.npz by tests/golden/make_sample_pair.py), normalised as main.lua:1095-1096 does.
+    Other sizes than 370 x 1226: the pair mirror-tiled (left / right and top / bottom reflections alternate, so no seams)
+    and cropped -- a second pair with real-scene arm statistics at 1000 x 1500."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_sample_pair.npz"))
+    l, r = z["left"].astype(np.float64), z["right"].astype(np.float64)
+    if H is not None and (H, W) != l.shape:
+        def tile(img):
+            h, w = img.shape
+            row = np.concatenate([img, img[:, ::-1]], 1)
+            row = np.tile(row, (1, W // (2 * w) + 1))[:, :W]
+            full = np.concatenate([row, row[::-1]], 0)
+            return np.tile(full, (H // (2 * h) + 1, 1))[:H]
+        l, r = tile(l), tile(r)
+    return normalize_image(l), normalize_image(r)
+
+
 def random_pair(H, W, seed=0):
     rng = np.random.default_rng(seed)
     return (normalize_image(rng.standard_normal((H, W))), normalize_image(rng.standard_normal((H, W))))
