@@ -276,7 +276,9 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		}
 		return 0;
 	};
-	const bool join_fits = (int64_t)W * ((D + 3) / 4 * 4) * 4 < ((int64_t)1 << 31) && ((int64_t)C * HW + W) * 4 < ((int64_t)1 << 31);
+	// (C + 64: the kernels pad the channel count to their k-step sizes and add channel offsets to range-checked 32-bit byte
+	// offsets -- no padded channel's offset may wrap)
+	const bool join_fits = (int64_t)W * ((D + 3) / 4 * 4) * 4 < ((int64_t)1 << 31) && ((int64_t)(C + 64) * HW + W) * 4 < ((int64_t)1 << 31);
 	if (from_feat && n_cbca1 == 0 && n_sgm > 0 && join_fits) {
 		// fast path: StereoJoin straight into (H,W,ds) with NaN fill and fix_border folded in
 		RUN(stereo_join_hwd(featL, featR, bufA[0], bufA[1], C, D, ds, H, W, p->border_n, st));

@@ -255,7 +255,7 @@ function adcensus.predict(o, dataset, arch, x_batch, input, disp_max, border_n, 
    p.median_k = 5
    p.sm_terminate = SM_TERMINATE[o.sm_terminate or ''] or error('unknown -sm_terminate ' .. tostring(o.sm_terminate))
    p.sm_skip = SM_SKIP[o.sm_skip or ''] or error('unknown -sm_skip ' .. tostring(o.sm_skip))
-   p.left_only = both and 0 or 1
+   p.left_only = (not both and dataset == 'mb') and 1 or 0   -- mb_directions, main.lua:953-955: dataset mb outside `-a predict` only
    local H, W = x_batch:size(3), x_batch:size(4)
    local C = arch == 'fast' and input:size(2) or 0
    local need = tonumber(lib.mc_predict_workspace_bytes(p, C, disp_max, H, W))

@@ -194,7 +194,8 @@ def main(argv=None):
         raw = raw_volumes_slow(features_slow(x_batch, layers), fc_layers, D, prm["border_n"])
         return stereo_predict_fused(x_batch, prm, D, raw=raw, workspace=workspace, want_volumes=want_volumes)
     if opt.a == "time":  # main.lua:1140-1167
-        prm["left_only"] = 1  # outside `-a predict` dataset mb runs direction -1 only (mb_directions, main.lua:953-955)
+        if dataset == "mb":
+            prm["left_only"] = 1  # outside `-a predict` dataset mb runs direction -1 only (mb_directions, main.lua:953-955)
         H, W, D = (240, 320, 32) if opt.tiny else ((350, 1242, 228) if dataset != "mb" else (1000, 1500, 200))
         x_batch = torch.empty((2, 1, H, W), dtype=torch.float32, device=dev).normal_()
         ws = Workspace(prm, D, H, W, dev)
