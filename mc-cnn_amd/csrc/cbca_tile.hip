@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : 1) cbca_tile_ke
 	const int wv_ = tid >> 6;
 	int step_no = 0;
 #endif
-	if (ys + TH < ye) fetch_rows(R, RR, TH, tid);   // the rows the second step adds
+	fetch_rows(R, RR, ys + TH < ye ? TH : 0, tid);   // the rows the second step adds
 	for (int y0 = ys, rrn = RR; y0 < ye; y0 += TH, rrn += TH) {
 		const bool more = y0 + TH < ye;
 #ifdef MC_TILE_PROF
@@ -438,7 +438,9 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : 1) cbca_tile_ke
 		// registers until the new loads are out -- so nothing here waits for a store to complete.
 		int tidc = tid0;
 		asm volatile("" : "+v"(tidc));   // (opaque: the per-thread index arithmetic of commit / fetch is redone per step instead of living in ~40 registers)
-		if (more) commit_rows(R, rrn, base, TH, tidc);   // relative row rrn = RR + k TH lives in slot (k TH) mod RR = base: the oldest rows go
+		// (no branch around the commit / the requests: on a path that skips them hipcc's wait-count model keeps the previous
+		// loads pending and protects their registers with full waits in the middle of the next step)
+		commit_rows(R, rrn, base, more ? TH : 0, tidc);   // relative row rrn = RR + k TH lives in slot (k TH) mod RR = base: the oldest rows go
 		TPROF(8);
 		// a wave stores whole rows through a descriptor that ends with the row: the words of a last unit that lie beyond the
 		// image (W not a multiple of 4) are dropped by the range check, rows beyond the region get an empty descriptor -- no branch
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : 1) cbca_tile_ke
 		}
 		for (int q = tid; q < NG * NKEY; q += NTHREADS) GHl[q] = 0;
 		if (tid == 0) CTRl[0] = 0;
-		if (y0 + 2 * TH < ye) fetch_rows(R, rrn + TH, TH, tidc);
+		fetch_rows(R, rrn + TH, y0 + 2 * TH < ye ? TH : 0, tidc);
 #pragma unroll
 		for (int k = 0; k < NO; ++k) asm volatile("" :: "v"(ov[k]));   // (the stored values keep their registers until here)
 		base += TH;
