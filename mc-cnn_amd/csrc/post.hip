@@ -445,13 +445,15 @@ int median2d(const float *img, float *out, int H, int W, int k, hipStream_t st)
 // ---- mean2d, adcensus.cu:1241-1261 ----------------------------------------------------------------
 // Range-gated Gaussian mean.  Tap order (xx outer, yy inner, running kernel index) and the FMA-contracted
 // `sum += img*k` are the reference's, so the result is bit-identical.
-// A 128-thread block produces a 64 x 8 output tile; a thread owns 4 vertically adjacent outputs, so one LDS read of
-// a tap column feeds up to 4 outputs (their windows overlap in all but 3 rows).  Image tile (+halo) and the (ks,ks)
+// A 256-thread block produces a 64 x 8 output tile; a thread owns 2 vertically adjacent outputs, so one LDS read of
+// a tap column feeds both (their windows overlap in all but one row).  (4 outputs per thread and 2 waves per block left the
+// chip with 1.8 waves per SIMD at KITTI size -- a lone wave issues an instruction every ~9 cycles; 2 per thread: 0.49 -> 0.44 ms
+// for the whole post-processing stage, 1 per thread the same.)  Image tile (+halo) and the (ks,ks)
 // weights live in LDS.  A tap that does not count adds w' = -0.0 instead of branching: x + (-0.0) == x and
 // fma(v, -0.0, s) == s for every finite v and every s this loop can hold (s starts at +0), so gated-out and
 // out-of-image taps (staged as a huge finite value) are exact no-ops.
-constexpr int M2_OY = 4;   // outputs per thread
-constexpr int M2_TR = 2;   // thread rows per block
+constexpr int M2_OY = 2;   // outputs per thread
+constexpr int M2_TR = 4;   // thread rows per block
 __global__ void __launch_bounds__(64 * M2_TR) mean2d_kernel(const float *__restrict__ img, const float *__restrict__ kernel,
                                                             float *__restrict__ out, int H, int W, int kr, float alpha2)
 {
@@ -489,20 +491,27 @@ __global__ void __launch_bounds__(64 * M2_TR) mean2d_kernel(const float *__restr
 	for (int ix = 0; ix < ks; ++ix) {
 		const float *col = tile + (ly * M2_OY) * TS + lx + ix;
 		const float *wc = wts + ix * WS + (M2_OY - 1);
-		float w1 = -0.0f, w2 = -0.0f, w3 = -0.0f;  // weights of taps j-1, j-2, j-3
+		float wprev[M2_OY > 1 ? M2_OY - 1 : 1];    // weights of taps j-1, j-2, ...
+#pragma unroll
+		for (int o = 0; o < M2_OY - 1; ++o) wprev[o] = -0.0f;
 #pragma unroll 4
 		for (int j = 0; j < nj; ++j) {
 			const float v = col[0];
 			col += TS;
 			const float w0 = wc[j];                  // -0.0 beyond the kernel
-			const float ws[M2_OY] = {w0, w1, w2, w3};  // output o sees this row as its tap j-o
+			float ws[M2_OY];                         // output o sees this row as its tap j-o
+			ws[0] = w0;
+#pragma unroll
+			for (int o = 1; o < M2_OY; ++o) ws[o] = wprev[o - 1];
 #pragma unroll
 			for (int o = 0; o < M2_OY; ++o) {
 				const float w = fabsf(v - c[o]) < alpha2 ? ws[o] : -0.0f;
 				sum[o] = fmaf(v, w, sum[o]);
 				cnt[o] += w;
 			}
-			w3 = w2; w2 = w1; w1 = w0;
+#pragma unroll
+			for (int o = M2_OY - 2; o > 0; --o) wprev[o] = wprev[o - 1];
+			if (M2_OY > 1) wprev[0] = w0;
 		}
 	}
 #pragma unroll
