@@ -586,7 +586,7 @@ def main():
                 acc["fc_stack"] = acc.get("fc_stack", 0.0) + e0.elapsed_time(e1) / reps
         acc.update(stage_times(step, reps))
         stage = {k: round(v, 4) for k, v in acc.items()}
-        roof = roofline_record(args.config, prm, H, W, D, C, acc, ms_per_step, device, xb)
+        roof = roofline_record(args.config + ("" if pair == PAIR_OF[args.config] else "_" + pair), prm, H, W, D, C, acc, ms_per_step, device, xb)
 
     if rank == 0 and fc_ws is not None and roof is not None:
         # the accurate net's dominant kernel is the FC stack: a dense fp32 GEMM chain on the matrix cores

@@ -19,8 +19,9 @@ def main(d, config):
             if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean over dispatches; source: " + d}
-    # cbca: one ITERATION over one volume = window kernel (L1 <= 5) or strip kernel + list kernel (L1 > 5): summed, not averaged
-    groups = {"sgm": ("sgm_pass_kernel",), "cbca": ("cbca_strip_kernel", "cbca_window_kernel", "cbca_list_kernel<"), "join": ("join_owner_kernel",),
+    # cbca: one ITERATION over one volume = the launches of cbca_by_arms (tile instances + strip kernel, all but one of which
+    # stand down at their first instruction): summed, not averaged
+    groups = {"sgm": ("sgm_pass_kernel",), "cbca": ("cbca_strip_kernel", "cbca_tile_kernel"), "join": ("join_owner_kernel",),
               "transpose": ("transpose_kernel",)}
     for g, pat in groups.items():
         ks = [k for k in acc if any(q in k for q in pat)]
