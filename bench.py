@@ -567,9 +567,36 @@ def main():
                 others_ok = others_ok and same_bits_dev(gathered[r], o)
                 checked.append(r)
                 del xb_r, kw_r
+        # where a step's time goes on every rank (outside the timed region): compute and gather timed separately, each behind
+        # a barrier so that a rank's figure is its own work and not its wait for the slowest peer; and the spread of the
+        # ranks' compute times (launch skew / a slow GPU shows up here, not in the aggregate)
+        nrep = max(3, min(10, args.steps))
+        comp = gath = 0.0
+        for _ in range(nrep):
+            sync()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            dist.barrier()
+            t3 = time.perf_counter()
+            gather()
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            comp += (t2 - t1) * 1e3 / nrep
+            gath += (t4 - t3) * 1e3 / nrep
+        mine = torch.tensor([comp, gath], dtype=torch.float64, device="cpu" if one_gpu else device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        comp_all = [round(float(t[0]), 4) for t in allr]
+        gath_all = [round(float(t[1]), 4) for t in allr]
         multi = dict(ranks_seen=ranks_seen, world_size=world, backend="gloo (MC_BENCH_ONE_GPU)" if one_gpu else "nccl (RCCL)",
                      own_slot_bit_exact_all_ranks=bool(flag.item()), ranks_recomputed_on_rank0=checked,
-                     gathered_equals_single_gpu=bool(others_ok))
+                     gathered_equals_single_gpu=bool(others_ok),
+                     per_rank_compute_ms=comp_all, per_rank_gather_ms=gath_all,
+                     compute_skew_ms=round(max(comp_all) - min(comp_all), 4),
+                     note="per-rank means over %d untimed steps: compute = one pair through mc_predict (device-synchronised), gather = "
+                          "the all-gather of the (H,W) maps entered by all ranks together; ms_per_step above times both back to back" % nrep)
 
     # live per-stage HIP-event timing (same stream) for the roofline
     roof = stage = None

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict_
 {
 	const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t HW = (int64_t)H * W;
-	bool unit = false;
+	bool unit = false, gt254 = false, gt4 = false, gt13 = false;
 	if (id < HW) {
 		const int x = (int)(id % W), y = (int)(id / W);
 		const int l = x - (int)arms[0 * HW + id] - 1;
@@ -110,15 +110,32 @@ __global__ void __launch_bounds__(256) cbca_pack_kernel(const float *__restrict_
 		const int d = (int)arms[3 * HW + id] - y - 1;
 		auto sat = [](int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
 		packed[id] = sat(l) | (sat(r) << 8) | (sat(u) << 16) | (sat(d) << 24);
-		if (l > 254 || r > 254 || u > 254 || d > 254) atomicOr(flags + CF_SATURATED, 1u);
-		if (l > 4 || r > 4 || u > 4 || d > 4) atomicOr(flags + CF_ARM_GT4, 1u);      // an arm beyond the tile kernel's short-arm instance (L1 <= 5)
-		if (l > 13 || r > 13 || u > 13 || d > 13) atomicOr(flags + CF_ARM_GT13, 1u);  // ... beyond its long-arm instance (L1 <= 14)
-		unit = l <= 1 && r <= 1 && u <= 1 && d <= 1;
+		const int longest = max(max(l, r), max(u, d));
+		gt254 = longest > 254;
+		gt4 = longest > 4;      // an arm beyond the tile kernel's short-arm instance (L1 <= 5)
+		gt13 = longest > 13;    // ... beyond its long-arm instance (L1 <= 14)
+		unit = longest <= 1;
 	}
+	// one atomic per BLOCK and flag, and none once a flag is up (on real scenes nearly every wave has an arm > 4: a million
+	// atomics on one word took 0.45 ms per image at 1000 x 1500)
+	__shared__ uint32_t blk[4];
+	if (threadIdx.x < 4) blk[threadIdx.x] = 0;
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	if (__any(gt254) && lane == 0) blk[0] = 1;
+	if (__any(gt4) && lane == 0) blk[1] = 1;
+	if (__any(gt13) && lane == 0) blk[2] = 1;
 	// pixels whose four arms are all at the minimum: where nearly every pixel of both images is one, nearly every support
 	// is the minimal 3 x 3 and aggregation is a bandwidth problem (the strip kernel's regime)
 	const unsigned long long m = __ballot(unit);
-	if ((threadIdx.x & 63) == 0 && m) atomicAdd(flags + CF_UNIT_PIXELS + image, (uint32_t)__builtin_popcountll(m));
+	if (lane == 0 && m) atomicAdd(&blk[3], (uint32_t)__builtin_popcountll(m));
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (blk[0] && !flags[CF_SATURATED]) atomicOr(flags + CF_SATURATED, 1u);
+		if (blk[1] && !flags[CF_ARM_GT4]) atomicOr(flags + CF_ARM_GT4, 1u);
+		if (blk[2] && !flags[CF_ARM_GT13]) atomicOr(flags + CF_ARM_GT13, 1u);
+		if (blk[3]) atomicAdd(flags + CF_UNIT_PIXELS + image, blk[3]);
+	}
 }
 
 // the kernel the pair's arms call for (one thread, after both cbca_pack_kernel launches)

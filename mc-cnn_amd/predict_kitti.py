@@ -80,13 +80,29 @@ def main(argv=None):
     prm = dict(TABLES[("kitti", "fast")])
     prm["border_n"] = len(layers)
 
+    # one HIP stream, one pinned staging buffer each way and one workspace per rank: uploads, the pipeline and the download of
+    # a pair are queued on the rank's own stream (the C ABI launches on torch's current stream) and the host waits once per pair
+    from .predict import Workspace
+    stream = torch.cuda.Stream(device=dev)
+    st = {"shape": None}
+
     def predict_pair(im0, im1):
         x0, x1 = mcmain.load_image(im0), mcmain.load_image(im1)
         if x0.shape[0] == 3:
             x0, x1 = mcmain.rgb2y(x0), mcmain.rgb2y(x1)
-        xb = torch.from_numpy(np.stack([mcmain.normalize(x0), mcmain.normalize(x1)])).to(dev)
-        res = stereo_predict_fused(xb, prm, opt.disp_max, feat=mcmain.features_fast(xb, layers))
-        return res["disp"].reshape(xb.shape[2:]).cpu().numpy()
+        host = np.stack([mcmain.normalize(x0), mcmain.normalize(x1)]).astype(np.float32)
+        if st["shape"] != host.shape:   # (KITTI pairs come in a few sizes)
+            H, W = host.shape[-2:]
+            st.update(shape=host.shape, pin_in=torch.empty(host.shape, dtype=torch.float32).pin_memory(),
+                      pin_out=torch.empty((H, W), dtype=torch.float32).pin_memory(),
+                      ws=Workspace(prm, opt.disp_max, H, W, dev))
+        st["pin_in"].copy_(torch.from_numpy(host))
+        with torch.cuda.stream(stream):
+            xb = st["pin_in"].to(dev, non_blocking=True)
+            res = stereo_predict_fused(xb, prm, opt.disp_max, feat=mcmain.features_fast(xb, layers), workspace=st["ws"])
+            st["pin_out"].copy_(res["disp"].reshape(xb.shape[2:]), non_blocking=True)
+        stream.synchronize()
+        return st["pin_out"].numpy().copy()
 
     err_sum, done = run(opt.action, opt.path, predict_pair, world, rank, n_pairs=opt.n)
     if opt.action == "test":
