@@ -1,5 +1,6 @@
 """CPU: the host side of `main.py` (main.lua's flag tables, image normalisation, seeded nets) -- no GPU needed."""
 import numpy as np
+import pytest
 
 from mc_cnn_amd import main as mcmain
 from mc_cnn_amd import params
@@ -314,3 +315,32 @@ def test_predict_kitti_host_logic(tmp_path):
     assert sorted(seen) == [0, 1, 2] and sorted(p.name for p in (tmp_path / "out").iterdir()) == ["%06d_10.png" % i for i in range(3)]
     back = binio.read_png16(str(tmp_path / "out" / "000001_10.png"))
     assert back.shape == (H, W)
+
+
+@pytest.mark.parametrize("name,mode", [("net_tiny_fast_ascii.t7", "ascii"), ("net_tiny_fast_binary.t7", "binary")])
+def test_t7_reader_on_fixtures_from_an_independent_writer(name, mode):
+    """tests/golden/net_tiny_fast_*.t7 were written by tests/golden/make_t7_fixture.c, a C restatement of torch7's WRITER side
+    (File.lua writeObject, Tensor / Storage write, THDiskFile's ASCII and binary conventions) that shares no code with the
+    reader: `{net_te, opt}` of a fast-architecture net whose four parameter tensors are views into ONE torch.CudaStorage
+    (written once, referenced by index afterwards), an nn.Sequential of cudnn.SpatialConvolution / cudnn.ReLU / nn.Normalize2 /
+    nn.StereoJoin1.  Still not a file written by Torch itself (none exists in the image): README says so."""
+    import os
+    from mc_cnn_amd import t7
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    obj = t7.load(path, mode=mode)
+    assert sorted(obj) == [1, 2]
+    net, opt = obj[1], obj[2]
+    assert net.cls == "nn.Sequential" and net["train"] is False
+    mods = [net["modules"][k] for k in sorted(net["modules"])]
+    assert [m.cls for m in mods] == ["cudnn.SpatialConvolution", "cudnn.ReLU", "cudnn.SpatialConvolution", "nn.Normalize2", "nn.StereoJoin1"]
+    assert mods[1]["inplace"] is True and mods[0]["nOutputPlane"] == 4 and mods[0]["padW"] == 1
+    assert opt == {"a": "train_all", "l1": 2, "fm": 4, "debug": False}
+    (w1, b1), (w2, b2) = t7.conv_layers(net)
+    exp = (0.5 * np.sin(0.37 * np.arange(188))).astype(np.float32)   # parameter k of the shared storage
+    assert w1.shape == (4, 1, 3, 3) and w2.shape == (4, 4, 3, 3)
+    assert np.array_equal(w1.ravel(), exp[:36]) and np.array_equal(b1, exp[36:40])
+    assert np.array_equal(w2.ravel(), exp[40:184]) and np.array_equal(b2, exp[184:188])
+    # main.py's loader takes the same file (main.lua:894-898)
+    if mode == "ascii":
+        convs, fcs = t7.load_reference_net(path, "fast")
+        assert fcs is None and len(convs) == 2 and np.array_equal(convs[0][0], w1) and np.array_equal(convs[1][1], b2)
