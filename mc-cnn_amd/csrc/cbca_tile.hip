@@ -103,7 +103,7 @@ __device__ __forceinline__ void tile_taps(const float *p, int n, float (&sum)[4]
 
 // P.gx x P.gy regions of TW columns x P.rb rows (a multiple of TH); a block takes one (region, plane)
 template <int A, int TW, int TH, int NWAVES, bool NT>
-__global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : 1) cbca_tile_kernel(const CbcaArgs P)
+__global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ? 4 : 1)) cbca_tile_kernel(const CbcaArgs P)
 {
 	using G = TileGeo<A, TW, TH>;
 	constexpr int AH = G::AH, SW = G::SW, RR = G::RR, NI = G::NI, NKEY = G::NKEY;
@@ -540,6 +540,7 @@ int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, 
 	switch (cfg.variant) {
 	case 1: return cbca_tiles_launch<13, 128, 32, 8>(P, nt, st);
 	case 2: return cbca_tiles_launch<13, 128, 16, 4>(P, nt, st);
+	case 3: return cbca_tiles_launch<13, 64, 16, 4>(P, nt, st);
 	default: return cbca_tiles_launch<13, 128, 16, 8>(P, nt, st);
 	}
 }
