@@ -157,8 +157,10 @@ function adcensus.cross(x0, out, L1, tau1)                   -- adcensus.cu:324-
    check(lib.mc_cross(ptr(x0, 'cross'), ptr(out, 'cross'), out:size(3), out:size(4), L1, tau1, nil), 'cross')
 end
 
--- adcensus.cbca, adcensus.cu:379-400, on the packed-arm strip kernel (mc_cbca_ws); the packed arm lengths live in a
--- scratch CudaTensor this module keeps and grows on demand (same stream, so reuse across calls is ordered).
+-- adcensus.cbca, adcensus.cu:379-400, through mc_cbca_ws: both images' arm lengths are packed into the scratch below, the
+-- library derives on the device which kernel the pair's arms call for (tile kernel short / long arms, strip kernel, one
+-- thread per voxel) and runs exactly that one -- nothing is kept between calls, nothing is read back by the host.  The packed
+-- arm lengths live in a scratch tensor that grows with the largest image seen.
 local cbca_scratch = torch.CudaTensor()
 function adcensus.cbca(x0c, x1c, vol_in, vol_out, direction)
    local D, H, W = vol_out:size(2), vol_out:size(3), vol_out:size(4)
