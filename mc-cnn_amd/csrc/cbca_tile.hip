@@ -8,9 +8,9 @@
 // first row to its own last row.  A lane therefore owns an ITEM = one column x 4 consecutive output rows: it walks the rows
 // from the topmost first row to the bottommost last row of its four outputs, fetches every run value ONCE from LDS and
 // adds it to all four accumulators; an accumulator is reset to +0.0 at its output's first row and read out after its last
-// row -- what it collected outside its own rows never reaches a result.  A lane whose own run is shorter than the wave's longest
-// ... is masked off: the lanes of a wave walk rows of different run lengths in lockstep under a shrinking EXEC mask.  Per tap
-// and wave: one ds_read_b32, one compare, four additions.
+// row -- what it collected outside its own rows never reaches a result.  The lanes of a wave walk rows of different run
+// lengths in lockstep under a shrinking EXEC mask (a lane whose run is over is masked off).  Per tap and wave: one
+// ds_read_b32, one compare, four additions.
 //
 // A block walks a strip of TW output columns of ONE disparity plane top to bottom in steps of TH rows.  An LDS ring of
 // TH + 2A rows holds the step's window: values (TW + the arm halo on either side), per pixel of the TW columns the run
