@@ -30,7 +30,7 @@ for it in range(n):
     if rng.random() < 0.3:
         prm["sm_skip"] = ["", "cbca", "sgm", "occlusion", "subpixel_enchancement", "median", "bilateral"][rng.integers(7)]
     kind = ["smooth", "blocky", "random", "natural", "natural"][rng.integers(5)]
-    if rng.random() < 0.25:   # arm limits between the parameter tables' (window kernel / strip + list boundary at L1 = 5 | 6)
+    if rng.random() < 0.25:   # arm limits between the parameter tables' (tile kernel short- / long-arm instance boundary at L1 = 5 | 6, strip kernel beyond 14)
         prm["L1"] = int(rng.integers(0, 20)); prm["tau1"] = float(rng.choice([0.02, 0.13, 0.5, 3.0]))
     x0, x1 = (smooth_pair(H, W, min(D, 8), seed=it) if kind == "smooth" else blocky_pair(H, W, seed=it) if kind == "blocky"
               else natural_pair(H, W, min(D, 8), seed=it, sigma=float(rng.choice([6.0, 15.0, 40.0]))) if kind == "natural"

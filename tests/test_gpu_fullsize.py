@@ -77,8 +77,8 @@ def test_fused_predict_at_benchmarked_shape(ref, mc, config):
 
 @pytest.mark.parametrize("preset,H,W,D", [("mb_slow", 260, 700, 48), ("kitti2015_slow", 200, 640, 64), ("mb_census", 130, 500, 40)])
 def test_fused_predict_on_real_scene_arm_statistics(ref, mc, preset, H, W, D):
-    """the regime real images are in (tests/util.natural_pair): cbca by window kernel (L1 <= 5) / strip kernel + the
-    pair's list of large supports (L1 > 5), both aggregation blocks, through mc_predict, against the reference's kernels"""
+    """the regime real images are in (tests/util.natural_pair): cbca by the tile kernel (short-arm instance for L1 <= 5, long-arm
+    instance for L1 <= 14, picked by the pair's route word), both aggregation blocks, through mc_predict, against the reference's kernels"""
     from ref_pipeline import ref_stereo_predict
     from mc_cnn_amd.predict import Workspace
     from util import natural_pair, raw_volumes
