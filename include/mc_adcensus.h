@@ -37,7 +37,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define MC_ABI_VERSION 5
+#define MC_ABI_VERSION 6
 #define MC_EINVAL (-22)
 #define MC_SGM_MAX_D 512   /* reference: __shared__ float[400], adcensus.cu:574 */
 #define MC_JOIN_MAX_C 128  /* reference: float L_cache[128], adcensus.cu:1460-1461 */
@@ -268,7 +268,12 @@ int mc_predict_timed(const mc_params *p, const float *x0, const float *x1,
  * 0 = default policy, 1 = non-temporal volume accesses), planes [d0, d0+nd) only (nd = 0: all), kernel `form`:
  * 0 = what mc_cbca_ws does, 1 = strip kernel (`rb` = output rows per strip, 0 = auto), 2 / 3 = tile kernel, short-arm /
  * long-arm instance (`rb` = tile geometry variant, 0 = the product's; the launch writes NOTHING if an arm exceeds 4 / 13).
+ * 4 / 5 = tile kernel (short- / long-arm instance) that also WRITES the pair's item order ("plan": what mc_predict keeps from
+ * the first aggregation pass of a direction for the other 17) behind the packed lengths, 6 / 7 = tile kernel that READS it:
+ * `scratch` must be 16-byte aligned and hold mc_cbca_scratch_bytes(H, W) + mc_cbca_plan_bytes(D, H, W) bytes, and a 6 / 7 call
+ * must follow a 4 / 5 call with the same arms, D, H, W, direction and scratch.
  * Lets small-shape parity tests reach what the benchmarked sizes and parameter sets select. */
+size_t mc_cbca_plan_bytes(int D, int H, int W);
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
                    int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
                    int rb, int nt, int d0, int nd, int form, void *stream);

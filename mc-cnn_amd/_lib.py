@@ -16,7 +16,7 @@ SYMBOLS = [
     "mc_argmin", "mc_spatial_argmin", "mc_outlier_detection", "mc_interpolate_occlusion",
     "mc_interpolate_mismatch", "mc_subpixel_enchancement", "mc_median2d", "mc_mean2d", "mc_gaussian_host",
     "mc_normalize_forward", "mc_predict_workspace_bytes", "mc_predict", "mc_predict_timed",
-    "mc_cbca_ws_cfg", "mc_transpose_cfg",
+    "mc_cbca_plan_bytes", "mc_cbca_ws_cfg", "mc_transpose_cfg",
 ]
 
 
@@ -31,6 +31,7 @@ def _load():
     lib.mc_last_error.restype = C.c_char_p
     lib.mc_sgm2_tmp_bytes.restype = C.c_size_t
     lib.mc_cbca_scratch_bytes.restype = C.c_size_t
+    lib.mc_cbca_plan_bytes.restype = C.c_size_t
     lib.mc_census_scratch_bytes.restype = C.c_size_t
     lib.mc_fc_stack_workspace_bytes.restype = C.c_size_t
     lib.mc_predict_workspace_bytes.restype = C.c_size_t
@@ -51,6 +52,7 @@ def _load():
         "mc_cross": [vp, vp, i, i, i, f, vp],
         "mc_cbca": [vp, vp, vp, vp, i, i, i, i, vp],
         "mc_cbca_scratch_bytes": [i, i],
+        "mc_cbca_plan_bytes": [i, i, i],
         "mc_cbca_ws": [vp, vp, vp, vp, i, i, i, i, vp, sz, vp],
         "mc_sgm2_tmp_bytes": [i, i, i],
         "mc_sgm2": [vp, vp, vp, vp, vp, sz, i, i, i, f, f, f, f, f, f, i, vp],
@@ -76,10 +78,10 @@ def _load():
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        if name not in ("mc_sgm2_tmp_bytes", "mc_cbca_scratch_bytes", "mc_census_scratch_bytes",
+        if name not in ("mc_sgm2_tmp_bytes", "mc_cbca_scratch_bytes", "mc_cbca_plan_bytes", "mc_census_scratch_bytes",
                         "mc_fc_stack_workspace_bytes", "mc_conv3x3_workspace_bytes"):
             fn.restype = C.c_int
-    if lib.mc_version() != 5:
+    if lib.mc_version() != 6:
         raise ImportError("mc-cnn_amd: ABI version mismatch")
     return lib
 

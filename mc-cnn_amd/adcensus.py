@@ -103,11 +103,12 @@ def cbca(x0c, x1c, vol_in, vol_out, direction):
 def cbca_cfg(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, d0=0, nd=0, form=0):
     """Test / bench hook (mc_cbca_ws_cfg): adcensus.cbca with the launch configuration forced -- non-temporal
     instantiation, plane range, kernel form (0 what adcensus.cbca does, 1 strip kernel with rb rows per strip, 2 / 3 tile
-    kernel short-arm / long-arm instance with rb = geometry variant; these write nothing if an arm exceeds 4 / 13) --
-    instead of derived from the problem."""
+    kernel short-arm / long-arm instance with rb = geometry variant; these write nothing if an arm exceeds 4 / 13;
+    4 / 5 tile kernel that also writes the pair's item order behind the packed lengths, 6 / 7 tile kernel that reads it:
+    a 6 / 7 call must follow a 4 / 5 call on the same arms, shape and direction) -- instead of derived from the problem."""
     _chk(x0c, x1c, vol_in, vol_out)
     D, H, W = vol_out.shape[-3:]
-    need = lib.mc_cbca_scratch_bytes(H, W)
+    need = lib.mc_cbca_scratch_bytes(H, W) + (lib.mc_cbca_plan_bytes(D, H, W) if form >= 4 else 0)
     scratch = _scratch_for(vol_out.device, need)
     check(lib.mc_cbca_ws_cfg(_p(x0c), _p(x1c), _p(vol_in), _p(vol_out), D, H, W, int(direction), scratch.data_ptr(), need,
                              int(rb), int(nt), int(d0), int(nd), int(form), _stream()), "cbca_cfg")

@@ -39,6 +39,7 @@ int cbca_if_overflow(const float *x0c, const float *x1c, const void *packed, con
                      int direction, hipStream_t st);
 int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int route,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
+size_t cbca_plan_bytes(int D, int H, int W);
 int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int route,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
 size_t conv3x3_workspace_bytes(int Cin, int Cout);
@@ -135,6 +136,7 @@ static int cbca_by_arms(const void *packed, const float *vin, float *vout, int D
 struct Plan {
 	int Dp;                 // padded pixel stride of the (H,W,Dp) volumes
 	size_t maps, arms, pack, vol, img, gk;
+	size_t cplan;           // per direction: the tile kernel's item order (cbca_tile.hip), 0 where it would not be reused
 	size_t total;
 };
 
@@ -151,7 +153,9 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	const int kr = (int)ceil(p->blur_sigma * 3);
 	const int ks = 2 * kr + 1;
 	pl.gk = align_up((size_t)ks * ks * sizeof(float), 256);
-	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk;
+	// the order of a step's items is the same in every aggregation pass over the pair: kept from the first pass on (~0.5 bytes per voxel)
+	pl.cplan = (p->cbca_i1 + p->cbca_i2 >= 2 && p->L1 - 1 <= 13) ? align_up(cbca_plan_bytes(D, H, W), 256) : 0;
+	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk + 2 * pl.cplan;
 	return pl;
 }
 
@@ -223,7 +227,9 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	bufC[1] = (float *)w; w += pl.vol;
 	float *img[6];
 	for (int i = 0; i < 6; ++i) { img[i] = (float *)w; w += pl.img; }
-	float *gk = (float *)w;
+	float *gk = (float *)w; w += pl.gk;
+	void *cplan[2] = {pl.cplan ? (void *)w : nullptr, pl.cplan ? (void *)(w + pl.cplan) : nullptr};
+	int cplan_passes[2] = {0, 0};   // aggregation passes so far: the first one writes the plan, the others read it
 	const int Dp = pl.Dp;
 	int rc;
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
@@ -268,7 +274,10 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 		for (int i = 0; i < n; ++i) {
 			for (int v = 0; v < nvol; ++v) {
 				float *dst = other(v);
-				const int rc2 = packed_ok ? cbca_by_arms(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st)
+				CbcaCfg cfg;
+				cfg.plan = cplan[v];
+				cfg.plan_mode = cplan[v] ? (cplan_passes[v]++ == 0 ? 1 : 2) : 0;
+				const int rc2 = packed_ok ? cbca_by_arms(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st, cfg)
 				                          : cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st);
 				if (rc2) return rc2;
 				cur[v] = dst;
@@ -566,6 +575,12 @@ int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *v
 	return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
 }
 
+size_t mc_cbca_plan_bytes(int D, int H, int W)
+{
+	if (!dims_ok(D, H, W)) return 0;
+	return align_up(cbca_scratch_bytes(H, W), 256) - cbca_scratch_bytes(H, W) + cbca_plan_bytes(D, H, W);
+}
+
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out, int D, int H, int W, int direction,
                    void *scratch, size_t scratch_bytes, int rb, int nt, int d0, int nd, int form, void *stream)
 {
@@ -577,13 +592,23 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
 	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws_cfg: image too large for 32-bit plane offsets");
-	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 3, "mc_cbca_ws_cfg: bad rb / nt / form");
+	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 7, "mc_cbca_ws_cfg: bad rb / nt / form");
 	MC_REQUIRE(d0 >= 0 && nd >= 0 && d0 + nd <= D, "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
 	CbcaCfg cfg;
 	cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd;
+	if (form >= 4) {   // tile kernel with the item order kept behind the packed lengths: 4 / 5 write it (short- / long-arm instance), 6 / 7 read it
+		const size_t off = align_up(cbca_scratch_bytes(H, W), 256);
+		MC_REQUIRE(scratch_bytes >= off + cbca_plan_bytes(D, H, W), "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu with the plan", scratch_bytes,
+		           off + cbca_plan_bytes(D, H, W));
+		MC_REQUIRE((uintptr_t)scratch % 16 == 0, "mc_cbca_ws_cfg: scratch must be 16-byte aligned for the plan");
+		cfg.plan = (char *)scratch + off;
+		cfg.plan_mode = form <= 5 ? 1 : 2;
+		const bool shortarm = form == 4 || form == 6;
+		return cbca_tiles(scratch, vol_in, vol_out, D, H, W, direction, shortarm ? 4 : 13, shortarm ? CR_ARMS_LE4 : CR_ARMS_LE13, st, cfg);
+	}
 	if (form >= 2) {   // tile kernel, short-arm (2) / long-arm (3) instance, rb = geometry variant; nothing is written if an arm exceeds 4 / 13
 		cfg.variant = rb;
 		return cbca_tiles(scratch, vol_in, vol_out, D, H, W, direction, form == 2 ? 4 : 13, form == 2 ? CR_ARMS_LE4 : CR_ARMS_LE13, st, cfg);

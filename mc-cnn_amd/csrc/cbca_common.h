@@ -31,6 +31,8 @@ struct CbcaArgs {
 	int route;
 	int gx, gy;                   // strips per row, row chunks
 	int d0, nd;                   // planes [d0, d0 + nd) of the volume are processed by this launch
+	void *plan;                   // tile kernel: the pair's item order per (plane, region, step), written by one launch and read by the others
+	int spr;                      // ... steps per region
 };
 
 

@@ -47,7 +47,8 @@ struct TileGeo {
 	static constexpr int M_BYTES = (RR * TW * 2 + 15) & ~15;   // runs: output columns only (a run is looked up in the item's own column)
 	static constexpr int UD_BYTES = (RR * TW + 15) & ~15;      // up | down << 4 per pixel, 0xff = no output here
 	static constexpr int OUT_BYTES = TH * TW * 4;
-	static constexpr int TAB_BYTES = NI * 2;
+	static constexpr int TAB_BYTES = NI * 2 + 16;          // sorted items, then (nz, nfast) of the step: one plan entry
+	static constexpr int ENT_BYTES = TAB_BYTES;            // plan entry of one (plane, region, step)
 	static constexpr int MISC_BYTES = NG * NKEY * 4 + 16;   // items per group and key; chunk counter
 	static constexpr int LDS_BYTES = V_BYTES + M_BYTES + UD_BYTES + OUT_BYTES + TAB_BYTES + MISC_BYTES;
 };
@@ -59,41 +60,63 @@ struct TileGeo {
 // after every group -- when the wave's longest run does.  Values are fetched nine at a time (0..8 up front: most rows
 // end there); rows with longer runs fetch 9..17 and 18..26 when they get there.  hipcc cannot express the EXEC narrowing,
 // hence the assembly; it waits for its own LDS reads (lgkmcnt(0)) before it uses them and restores EXEC.
-#define MC_TAP(t, v) "v_cmpx_lt_u32_e32 vcc, " #t ", %[n]\n v_add_f32 %[s0], %[s0], %[" #v "]\n v_add_f32 %[s1], %[s1], %[" #v "]\n" \
-                     " v_add_f32 %[s2], %[s2], %[" #v "]\n v_add_f32 %[s3], %[s3], %[" #v "]\n"
+#define MC_ADD1(v) " v_add_f32 %[s0], %[s0], %[" #v "]\n"
+#define MC_ADD2(v) MC_ADD1(v) " v_add_f32 %[s1], %[s1], %[" #v "]\n"
+#define MC_ADD3(v) MC_ADD2(v) " v_add_f32 %[s2], %[s2], %[" #v "]\n"
+#define MC_ADD4(v) MC_ADD3(v) " v_add_f32 %[s3], %[s3], %[" #v "]\n"
+#define MC_TAP(K, t, v) "v_cmpx_lt_u32_e32 vcc, " #t ", %[n]\n" MC_ADD##K(v)
 #define MC_LOAD9(o) "ds_read_b32 %[v0], %[p] offset:" #o "+0\n ds_read_b32 %[v1], %[p] offset:" #o "+4\n ds_read_b32 %[v2], %[p] offset:" #o "+8\n" \
                     " ds_read_b32 %[v3], %[p] offset:" #o "+12\n ds_read_b32 %[v4], %[p] offset:" #o "+16\n ds_read_b32 %[v5], %[p] offset:" #o "+20\n" \
                     " ds_read_b32 %[v6], %[p] offset:" #o "+24\n ds_read_b32 %[v7], %[p] offset:" #o "+28\n ds_read_b32 %[v8], %[p] offset:" #o "+32\n"
 #define MC_EXIT "s_nop 1\n s_cbranch_execz .Ltaps_done_%=\n"
-template <bool LONG>   // LONG: runs up to 27 values (arms <= 13), else up to 9 (arms <= 4)
-__device__ __forceinline__ void tile_taps(const float *p, int n, float (&sum)[4])
+#define MC_TAPS_9(K) "s_mov_b64 %[sv], exec\n" MC_LOAD9(0) "s_waitcnt lgkmcnt(0)\n" \
+	MC_TAP(K, 0, v0) MC_TAP(K, 1, v1) MC_TAP(K, 2, v2) MC_EXIT MC_TAP(K, 3, v3) MC_TAP(K, 4, v4) MC_EXIT \
+	MC_TAP(K, 5, v5) MC_TAP(K, 6, v6) MC_TAP(K, 7, v7) MC_TAP(K, 8, v8)
+#define MC_TAPS_27(K) MC_TAPS_9(K) MC_EXIT MC_LOAD9(36) "s_waitcnt lgkmcnt(0)\n" \
+	MC_TAP(K, 9, v0) MC_TAP(K, 10, v1) MC_TAP(K, 11, v2) MC_TAP(K, 12, v3) MC_EXIT MC_TAP(K, 13, v4) MC_TAP(K, 14, v5) MC_TAP(K, 15, v6) MC_TAP(K, 16, v7) \
+	MC_TAP(K, 17, v8) MC_EXIT MC_LOAD9(72) "s_waitcnt lgkmcnt(0)\n" \
+	MC_TAP(K, 18, v0) MC_TAP(K, 19, v1) MC_TAP(K, 20, v2) MC_TAP(K, 21, v3) MC_TAP(K, 22, v4) MC_EXIT MC_TAP(K, 23, v5) MC_TAP(K, 24, v6) MC_TAP(K, 25, v7) \
+	MC_TAP(K, 26, v8)
+#define MC_TAPS_END ".Ltaps_done_%=:\n s_mov_b64 exec, %[sv]\n"
+#define MC_TAPS_TMPS [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7), \
+	[v8] "=&v"(v8), [sv] "=&s"(sv)
+// pa: LDS byte address of the run's first value.  LONG: runs up to 27 values (arms <= 13), else up to 9 (arms <= 4).
+template <bool LONG>
+__device__ __forceinline__ void tile_taps(unsigned pa, int n, float (&sum)[4])
 {
 	float v0, v1, v2, v3, v4, v5, v6, v7, v8;
 	unsigned long long sv;
-	const unsigned pa = (unsigned)(size_t)p;   // LDS byte address
-	if (LONG) {
-		asm volatile("s_mov_b64 %[sv], exec\n" MC_LOAD9(0) "s_waitcnt lgkmcnt(0)\n"
-		             MC_TAP(0, v0) MC_TAP(1, v1) MC_TAP(2, v2) MC_EXIT MC_TAP(3, v3) MC_TAP(4, v4) MC_EXIT
-		             MC_TAP(5, v5) MC_TAP(6, v6) MC_TAP(7, v7) MC_TAP(8, v8) MC_EXIT
-		             MC_LOAD9(36) "s_waitcnt lgkmcnt(0)\n"
-		             MC_TAP(9, v0) MC_TAP(10, v1) MC_TAP(11, v2) MC_TAP(12, v3) MC_EXIT MC_TAP(13, v4) MC_TAP(14, v5) MC_TAP(15, v6) MC_TAP(16, v7) MC_TAP(17, v8) MC_EXIT
-		             MC_LOAD9(72) "s_waitcnt lgkmcnt(0)\n"
-		             MC_TAP(18, v0) MC_TAP(19, v1) MC_TAP(20, v2) MC_TAP(21, v3) MC_TAP(22, v4) MC_EXIT MC_TAP(23, v5) MC_TAP(24, v6) MC_TAP(25, v7) MC_TAP(26, v8)
-		             ".Ltaps_done_%=:\n s_mov_b64 exec, %[sv]\n"
-		             : [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3]), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2),
-		               [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7), [v8] "=&v"(v8), [sv] "=&s"(sv)
-		             : [n] "v"(n), [p] "v"(pa)
-		             : "vcc", "memory");
-	} else {
-		asm volatile("s_mov_b64 %[sv], exec\n" MC_LOAD9(0) "s_waitcnt lgkmcnt(0)\n"
-		             MC_TAP(0, v0) MC_TAP(1, v1) MC_TAP(2, v2) MC_EXIT MC_TAP(3, v3) MC_TAP(4, v4) MC_EXIT
-		             MC_TAP(5, v5) MC_TAP(6, v6) MC_TAP(7, v7) MC_TAP(8, v8)
-		             ".Ltaps_done_%=:\n s_mov_b64 exec, %[sv]\n"
-		             : [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3]), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2),
-		               [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7), [v8] "=&v"(v8), [sv] "=&s"(sv)
-		             : [n] "v"(n), [p] "v"(pa)
-		             : "vcc", "memory");
-	}
+	if (LONG)
+		asm volatile(MC_TAPS_27(4) MC_TAPS_END : [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3]), MC_TAPS_TMPS
+		             : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+	else
+		asm volatile(MC_TAPS_9(4) MC_TAPS_END : [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3]), MC_TAPS_TMPS
+		             : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+}
+// ... for one, two, three accumulators (rows of the three-row class, which feed a fixed set of outputs)
+template <bool LONG>
+__device__ __forceinline__ void tile_taps1(unsigned pa, int n, float &a)
+{
+	float v0, v1, v2, v3, v4, v5, v6, v7, v8;
+	unsigned long long sv;
+	if (LONG) asm volatile(MC_TAPS_27(1) MC_TAPS_END : [s0] "+v"(a), MC_TAPS_TMPS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+	else asm volatile(MC_TAPS_9(1) MC_TAPS_END : [s0] "+v"(a), MC_TAPS_TMPS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+}
+template <bool LONG>
+__device__ __forceinline__ void tile_taps2(unsigned pa, int n, float &a, float &b)
+{
+	float v0, v1, v2, v3, v4, v5, v6, v7, v8;
+	unsigned long long sv;
+	if (LONG) asm volatile(MC_TAPS_27(2) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), MC_TAPS_TMPS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+	else asm volatile(MC_TAPS_9(2) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), MC_TAPS_TMPS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+}
+template <bool LONG>
+__device__ __forceinline__ void tile_taps3(unsigned pa, int n, float &a, float &b, float &c)
+{
+	float v0, v1, v2, v3, v4, v5, v6, v7, v8;
+	unsigned long long sv;
+	if (LONG) asm volatile(MC_TAPS_27(3) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), [s2] "+v"(c), MC_TAPS_TMPS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+	else asm volatile(MC_TAPS_9(3) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), [s2] "+v"(c), MC_TAPS_TMPS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
 }
 #undef MC_TAP
 #undef MC_LOAD9
@@ -101,8 +124,12 @@ __device__ __forceinline__ void tile_taps(const float *p, int n, float (&sum)[4]
 
 }  // namespace
 
-// P.gx x P.gy regions of TW columns x P.rb rows (a multiple of TH); a block takes one (region, plane)
-template <int A, int TW, int TH, int NWAVES, bool NT>
+// P.gx x P.gy regions of TW columns x P.rb rows (a multiple of TH); a block takes one (region, plane).
+// The order of a step's items depends on the pair's arms and the plane only -- not on the volume -- and a pair is aggregated many
+// times over (main.lua:998-1001, 1033-1039: 2 + 16 iterations per direction on Middlebury).  MODE 1: the launch sorts and also
+// writes every step's table + (nz, nfast) to P.plan; MODE 2: it reads them a step ahead, together with the rows, and has no sort
+// pass and two barriers per step instead of four; MODE 0: no plan (adcensus.cbca called on its own).
+template <int A, int TW, int TH, int NWAVES, bool NT, int MODE>
 __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ? 4 : 1)) cbca_tile_kernel(const CbcaArgs P)
 {
 	using G = TileGeo<A, TW, TH>;
@@ -143,6 +170,14 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
 	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(P.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(P.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
+	// outputs with a partner: columns [lo, lo + span) (adcensus.cu:353); the others are copied through
+	const int lo = max(0, -sh);
+	const cb_u32 span = (cb_u32)max(0, min(W, W - sh) - lo);
+	const bool edge_tile = tx0 < lo || tx0 + TW > lo + (int)span;   // (block-uniform)
+	constexpr int ENT = G::ENT_BYTES;
+	const int nsteps = (ye - ys + TH - 1) / TH;
+	const __amdgpu_buffer_rsrc_t rplan = __builtin_amdgcn_make_buffer_rsrc(
+		MODE ? (void *)((char *)P.plan + ((size_t)d * (size_t)(P.gx * P.gy) + (size_t)region) * (size_t)P.spr * ENT) : nullptr, 0, MODE ? P.spr * ENT : 0, 0x00020000);
 
 	for (int q = tid; q < NG * NKEY; q += NTHREADS) GHl[q] = 0;
 	if (tid == 0) CTRl[0] = 0;
@@ -196,13 +231,12 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			int slot = slot0 + r;
 			slot = slot >= RR ? slot - RR : slot;
 			const int y = yr0 + rr0 + r, x = tx0 + 4 * u;
-			const bool rok = y >= 0 && y < H;
+			const cb_u32 spanr = (y >= 0 && y < H) ? span : 0u;   // pixel exists, partner inside the image (adcensus.cu:353)
 			const cb_u32 mm[4] = {bytemin4(R.a[k].x, R.b[k].x), bytemin4(R.a[k].y, R.b[k].y), bytemin4(R.a[k].z, R.b[k].z), bytemin4(R.a[k].w, R.b[k].w)};
 			cb_u32 run[4], ud[4];
 #pragma unroll
 			for (int t = 0; t < 4; ++t) {
-				const int xc = x + t;
-				const bool ok = rok && xc < W && xc + sh >= 0 && xc + sh < W;   // pixel exists, partner inside the image (adcensus.cu:353)
+				const bool ok = (cb_u32)(x + t - lo) < spanr;
 				const cb_u32 l = mm[t] & 0xffu, rr = (mm[t] >> 8) & 0xffu;
 				run[t] = ok ? ((4u * l) | ((l + rr + 1u) << 8)) : 0u;
 				ud[t] = ok ? (((mm[t] >> 16) & 15u) | ((mm[t] >> 20) & 0xf0u)) : 0xffu;
@@ -212,11 +246,24 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 		}
 	};
 
+	// plan entry of step s -> registers -> the item table (MODE 2); threads 0 .. NI/4 - 1 carry four items each, the next two the header
+	cb_u2 tabr = {0u, 0u};
+	auto fetch_tab = [&](int s, int tid) {
+		tabr = __builtin_amdgcn_raw_buffer_load_b64(rplan, (tid <= NI / 4 + 1 && s < nsteps) ? (cb_u32)(s * ENT + tid * 8) : OOB, 0, 0);
+	};
+	auto commit_tab = [&](int tid) {
+		if (tid <= NI / 4 + 1) *(cb_u2 *)(TABl + 4 * tid) = tabr;
+	};
+
 	Rows R;
 	for (int rr0 = 0; rr0 < RR; rr0 += TH) {   // the first step's window
 		const int nrows = min(TH, RR - rr0);
 		fetch_rows(R, rr0, nrows, tid);
 		commit_rows(R, rr0, rr0, nrows, tid);
+	}
+	if (MODE == 2) {
+		fetch_tab(0, tid);
+		commit_tab(tid);
 	}
 	__syncthreads();
 
@@ -226,7 +273,9 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	int step_no = 0;
 #endif
 	fetch_rows(R, RR, ys + TH < ye ? TH : 0, tid);   // the rows the second step adds
-	for (int y0 = ys, rrn = RR; y0 < ye; y0 += TH, rrn += TH) {
+	if (MODE == 2) fetch_tab(1, tid);
+	int sidx = 0;   // step of the region
+	for (int y0 = ys, rrn = RR; y0 < ye; y0 += TH, rrn += TH, ++sidx) {
 		const bool more = y0 + TH < ye;
 #ifdef MC_TILE_PROF
 		const bool prof_on = blockIdx.x == gridDim.x / 2 + 8 && step_no < 12;
@@ -234,7 +283,19 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 		TPROF(0);
 		TPROF(1);
 
-		// ---- items sorted by height (tallest first): counting sort ----------------------------------------------------
+		// ---- outputs without a partner are copied through (adcensus.cu:353-354): whole columns, and only in tiles that reach
+		// beyond [lo, lo + span).  (Pixels outside the image never leave the tile: the row stores below are clipped.)
+		if (edge_tile) {
+			for (int q = tid0; q < TH * TW; q += NTHREADS) {
+				const int r = q / TW, cc = q - r * TW;
+				if ((cb_u32)(tx0 + cc - lo) >= span) {
+					int slot = base + A + r;
+					slot = slot >= RR ? slot - RR : slot;
+					OUTl[q] = Vl[slot * SW + AH + cc];
+				}
+			}
+		}
+
 		// item i = (column c, row group g): outputs window rows A + 4g .. A + 4g + 3 of column c; height = rows from the topmost
 		// first row to the bottommost last row of its outputs that have a partner.  Window rows 0 .. RR - 1, ring slot of
 		// window row w = (base + w) mod RR.
@@ -256,94 +317,112 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			}
 			return udall;
 		};
-		// key of an item: 0 = nothing to compute, 1 = its four supports are all the minimal 3 x 3, else height + 1.  The sort is
-		// STABLE (ballot ranks inside a group of 64 consecutive columns, per-group counts, one scan): neighbouring columns of
-		// one class stay neighbouring lanes, so a chunk's LDS reads are mostly consecutive words.
-		const int wv = wvs;
-		int lanes = tid0 & 63;
-		asm volatile("" : "+v"(lanes));   // (opaque per step, as tidc below)
-		constexpr int IPT = NG / NWAVES;
-		cb_u32 keyrank[IPT];
+		int nz, nfast, ngen;   // items [0, ngen): general walk, [ngen, nfast): three-row class, [nfast, nz): four 3 x 3 supports
+		if constexpr (MODE != 2) {
+			// ---- items sorted by height (tallest first): counting sort ------------------------------------------------
+			// key of an item: 0 = nothing to compute, 1 = its four supports are all the minimal 3 x 3, 2 = its four outputs all reach
+			// exactly one row up and down (six rows, row r feeds outputs max(0, r - 2) .. min(3, r): no per-lane bookkeeping), else
+			// height + 1 (heights 1 and 2 share key 3).  Ranks inside
+			// a group of 64 consecutive columns, per-group counts, one scan: neighbouring columns of one class stay neighbouring
+			// lanes, so a chunk's LDS reads are mostly consecutive words.
+			const int wv = wvs;
+			int lanes = tid0 & 63;
+			asm volatile("" : "+v"(lanes));   // (opaque per step, as tidc below)
+			constexpr int IPT = NG / NWAVES;
+			cb_u32 keyrank[IPT];
 #pragma unroll
-		for (int k = 0; k < IPT; ++k) {
-			const int gi = wv + k * NWAVES, i = gi * 64 + lanes;
-			const int c = i % TW, g = i / TW;
-			int s0[4], e0[4], top, bot;
-			const cb_u32 udall = item_rows(c, g, s0, e0, top, bot);
-			int key = bot >= top ? bot - top + 2 : 0;
-			if (udall == 0x11111111u) {   // all four outputs reach one row up and down: 3 x 3 each if the six rows' runs are (1, 1)
-				bool mini = true;
-				int slot = base + A + 4 * g - 1;
-				slot = slot >= RR ? slot - RR : slot;
+			for (int k = 0; k < IPT; ++k) {
+				const int gi = wv + k * NWAVES, i = gi * 64 + lanes;
+				const int c = i % TW, g = i / TW;
+				int s0[4], e0[4], top, bot;
+				const cb_u32 udall = item_rows(c, g, s0, e0, top, bot);
+				int key = bot >= top ? max(bot - top + 2, 3) : 0;
+				if (udall == 0x11111111u) {   // all four outputs reach one row up and down: 3 x 3 each if the six rows' runs are (1, 1)
+					bool mini = true;
+					int slot = base + A + 4 * g - 1;
+					slot = slot >= RR ? slot - RR : slot;
 #pragma unroll
-				for (int r = 0; r < 6; ++r) {
-					mini = mini && Ml[slot * TW + c] == 0x0304u;
-					slot = slot + 1 == RR ? 0 : slot + 1;
+					for (int r = 0; r < 6; ++r) {
+						mini = mini && Ml[slot * TW + c] == 0x0304u;
+						slot = slot + 1 == RR ? 0 : slot + 1;
+					}
+					key = mini ? 1 : 2;
 				}
-				key = mini ? 1 : key;
+#ifdef MC_TILE_RANK_BALLOT
+				cb_u32 rank = 0;
+				unsigned long long rem = ~0ull;
+				while (rem) {   // one pass per distinct key of the group
+					const int leader = __builtin_ctzll(rem);
+					const int k0 = __builtin_amdgcn_readlane(key, leader);
+					const unsigned long long m = __ballot(key == k0);
+					if (key == k0) rank = __builtin_amdgcn_mbcnt_hi((cb_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)m, 0));
+					if (lane == leader) GHl[gi * NKEY + k0] = (cb_u32)__builtin_popcountll(m);
+					rem &= ~m;
+				}
+#else
+				// rank inside (group, key): one LDS atomic per item (the order among equal keys is whatever the LDS serves -- lane
+				// order in practice -- and changes no result: every output is computed by exactly one lane, whichever it is)
+				const cb_u32 rank = atomicAdd(&GHl[gi * NKEY + key], 1u);
+#endif
+				keyrank[k] = (cb_u32)key | (rank << 8);
 			}
-			cb_u32 rank = 0;
-			unsigned long long rem = ~0ull;
-			while (rem) {   // one pass per distinct key of the group
-				const int leader = __builtin_ctzll(rem);
-				const int k0 = __builtin_amdgcn_readlane(key, leader);
-				const unsigned long long m = __ballot(key == k0);
-				if (key == k0) rank = __builtin_amdgcn_mbcnt_hi((cb_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)m, 0));
-				if (lane == leader) GHl[gi * NKEY + k0] = (cb_u32)__builtin_popcountll(m);
-				rem &= ~m;
-			}
-			keyrank[k] = (cb_u32)key | (rank << 8);
-			// outputs without a partner are copied through (adcensus.cu:353-354); pixels outside the image never leave the tile
-			int oslot = base + A + 4 * g;
+			TPROF(2);
+			__syncthreads();
+			TPROF(3);
+			// counts -> positions, in every wave for itself (no second barrier): lane l owns key l.  Keys descending, inside a key
+			// group after group.
+			cb_u32 posbase[IPT];
+			{
+				cb_u32 total = 0, pre[IPT];
 #pragma unroll
-			for (int j = 0; j < 4; ++j, ++oslot) {
-				oslot = oslot >= RR ? oslot - RR : oslot;
-				if (((udall >> (8 * j)) & 0xffu) == 0xffu) OUTl[(4 * g + j) * TW + c] = Vl[oslot * SW + c + AH];
+				for (int k = 0; k < IPT; ++k) pre[k] = 0;
+#pragma unroll
+				for (int gi = 0; gi < NG; ++gi) {
+					const cb_u32 n = lane < NKEY ? GHl[gi * NKEY + lane] : 0u;
+#pragma unroll
+					for (int k = 0; k < IPT; ++k) pre[k] = gi == wv + k * NWAVES ? total : pre[k];
+					total += n;
+				}
+				// inclusive scan over the keys (lanes 0 .. 31): DPP row shifts, then row 0's sum into row 1
+				cb_u32 sc = total;
+				sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xF, 0xF, false);   // row_shr:1
+				sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xF, 0xF, false);   // row_shr:2
+				sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xF, 0xF, false);   // row_shr:4
+				sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x118, 0xF, 0xF, false);   // row_shr:8
+				sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, DPP_ROW_BCAST15, 0xA, 0xF, false);
+				const cb_u32 all = (cb_u32)__builtin_amdgcn_readlane((int)sc, NKEY - 1);
+				const cb_u32 above = all - sc;   // items of larger keys
+				nz = NI - __builtin_amdgcn_readlane((int)total, 0);           // items with at least one output to compute
+				nfast = nz - __builtin_amdgcn_readlane((int)total, 1);        // ... of which the last ones are four 3 x 3 supports each
+				ngen = nfast - __builtin_amdgcn_readlane((int)total, 2);      // ... preceded by the three-row class
+#pragma unroll
+				for (int k = 0; k < IPT; ++k) posbase[k] = above + pre[k];
 			}
+#pragma unroll
+			for (int k = 0; k < IPT; ++k) {
+				const int gi = wv + k * NWAVES, i = gi * 64 + lanes;
+				const int c = i % TW, g = i / TW;
+				const cb_u32 key = keyrank[k] & 0xffu, rank = keyrank[k] >> 8;
+				const cb_u32 first = (cb_u32)__builtin_amdgcn_ds_bpermute((int)(key * 4u), (int)posbase[k]);
+				TABl[first + rank] = (unsigned short)(c | (g << 8));
+			}
+			TPROF(4);
+			__syncthreads();
+			TPROF(5);
+			if constexpr (MODE == 1) {   // the finished table (and the two counts behind it) -> this step's plan entry
+				int tw = tid0;
+				asm volatile("" : "+v"(tw));
+				cb_u2 ent2 = *(const cb_u2 *)(TABl + 4 * (tw <= NI / 4 ? tw : 0));
+				if (tw == NI / 4) ent2 = cb_u2{(cb_u32)nz, (cb_u32)nfast};
+				if (tw == NI / 4 + 1) ent2 = cb_u2{(cb_u32)ngen, 0u};
+				__builtin_amdgcn_raw_buffer_store_b64(ent2, rplan, tw <= NI / 4 + 1 ? (cb_u32)(sidx * ENT + tw * 8) : OOB, 0, 0);
+			}
+		} else {
+			const cb_u32 *hdr = (const cb_u32 *)(TABl + NI);
+			nz = min(__builtin_amdgcn_readfirstlane((int)hdr[0]), NI);   // (clamped: an entry nobody wrote must not turn into a long loop)
+			nfast = __builtin_amdgcn_readfirstlane((int)hdr[1]);
+			ngen = __builtin_amdgcn_readfirstlane((int)hdr[2]);
 		}
-		TPROF(2);
-		__syncthreads();
-		TPROF(3);
-		// counts -> positions, in every wave for itself (no second barrier): lane l owns key l.  Keys descending, inside a key
-		// group after group.
-		cb_u32 posbase[IPT];
-		int nz, nfast;
-		{
-			cb_u32 total = 0, pre[IPT];
-#pragma unroll
-			for (int k = 0; k < IPT; ++k) pre[k] = 0;
-#pragma unroll
-			for (int gi = 0; gi < NG; ++gi) {
-				const cb_u32 n = lane < NKEY ? GHl[gi * NKEY + lane] : 0u;
-#pragma unroll
-				for (int k = 0; k < IPT; ++k) pre[k] = gi == wv + k * NWAVES ? total : pre[k];
-				total += n;
-			}
-			// inclusive scan over the keys (lanes 0 .. 31): DPP row shifts, then row 0's sum into row 1
-			cb_u32 sc = total;
-			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xF, 0xF, false);   // row_shr:1
-			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xF, 0xF, false);   // row_shr:2
-			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xF, 0xF, false);   // row_shr:4
-			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x118, 0xF, 0xF, false);   // row_shr:8
-			sc += (cb_u32)__builtin_amdgcn_update_dpp(0, (int)sc, DPP_ROW_BCAST15, 0xA, 0xF, false);
-			const cb_u32 all = (cb_u32)__builtin_amdgcn_readlane((int)sc, NKEY - 1);
-			const cb_u32 above = all - sc;   // items of larger keys
-			nz = NI - __builtin_amdgcn_readlane((int)total, 0);           // items with at least one output to compute
-			nfast = nz - __builtin_amdgcn_readlane((int)total, 1);        // ... of which the last ones are four 3 x 3 supports each
-#pragma unroll
-			for (int k = 0; k < IPT; ++k) posbase[k] = above + pre[k];
-		}
-#pragma unroll
-		for (int k = 0; k < IPT; ++k) {
-			const int gi = wv + k * NWAVES, i = gi * 64 + lanes;
-			const int c = i % TW, g = i / TW;
-			const cb_u32 key = keyrank[k] & 0xffu, rank = keyrank[k] >> 8;
-			const cb_u32 first = (cb_u32)__builtin_amdgcn_ds_bpermute((int)(key * 4u), (int)posbase[k]);
-			TABl[first + rank] = (unsigned short)(c | (g << 8));
-		}
-		TPROF(4);
-		__syncthreads();
-		TPROF(5);
 		const int nchunks = (nz + 63) >> 6;
 
 		// ---- chunks of 64 items, tallest first ----------------------------------------------------------------------
@@ -376,57 +455,96 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 					if (has) OUTl[(4 * g + j) * TW + c] = fs[j] / 9.0f;
 				continue;
 			}
+			if (chunk * 64 >= ngen) {
+				// every item of the chunk has four outputs of three rows each (the minimal class's items at its end included): window
+				// row r of the item's six is row r - j of output j, so it feeds outputs max(0, r - 2) .. min(3, r) -- no first / last
+				// rows to watch, only the runs to look up
+				int slot = base + A + 4 * g - 1;
+				slot = slot >= RR ? slot - RR : slot;
+				const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;
+				float fs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+				int nr[6];
+#pragma unroll
+				for (int r = 0; r < 6; ++r) {
+					const cb_u32 m = has ? (cb_u32)Ml[slot * TW + c] : 0u;
+					nr[r] = (int)(m >> 8);
+					const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
+					slot = slot + 1 == RR ? 0 : slot + 1;
+					if (r == 0) tile_taps1<(A > 4)>(pa, nr[r], fs[0]);
+					else if (r == 1) tile_taps2<(A > 4)>(pa, nr[r], fs[0], fs[1]);
+					else if (r == 2) tile_taps3<(A > 4)>(pa, nr[r], fs[0], fs[1], fs[2]);
+					else if (r == 3) tile_taps3<(A > 4)>(pa, nr[r], fs[1], fs[2], fs[3]);
+					else if (r == 4) tile_taps2<(A > 4)>(pa, nr[r], fs[2], fs[3]);
+					else tile_taps1<(A > 4)>(pa, nr[r], fs[3]);
+				}
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					if (has) OUTl[(4 * g + j) * TW + c] = fs[j] / (float)(nr[j] + nr[j + 1] + nr[j + 2]);
+				continue;
+			}
 			int s0[4], e0[4], top, bot;
 			item_rows(c, g, s0, e0, top, bot);
 			const int ext = has ? bot - top + 1 : 0;
-			// lane 0 holds the chunk's tallest item -- except that the 3 x 3 class (six rows) is sorted behind every other class
-			const int E = max(__builtin_amdgcn_readfirstlane(ext), chunk * 64 + 64 > nfast ? 6 : 0);
-			int srel[4], erel[4];
+			// lane 0 holds the chunk's tallest item -- except that heights 1 and 2 share a key and that the six-row classes are sorted
+			// behind every other class
+			const int E = max(max(__builtin_amdgcn_readfirstlane(ext), 2), chunk * 64 + 64 > ngen ? 6 : 0);
+#ifndef MC_TILE_NO_SETPRIO
+			if (E >= 14) __builtin_amdgcn_s_setprio(2);   // a tall chunk is the step's critical path (one wave, a chain of thousands of instructions)
+#endif
+			// first / last row of output j, counted from the item's top, as one-hot words (0: no such output): the walk below tests
+			// them against the row's bit with one compare each
+			cb_u32 sbit[4], ebit[4];
+			bool outj[4];
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
-				srel[j] = has ? s0[j] - top : 1 << 20;
-				erel[j] = has ? e0[j] - top : -1;
+				outj[j] = has && e0[j] >= 0;
+				sbit[j] = outj[j] ? 1u << (s0[j] - top) : 0u;
+				ebit[j] = outj[j] ? 1u << (e0[j] - top) : 0u;
 			}
 			float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-			int cb[4] = {0, 0, 0, 0}, cnt[4] = {1, 1, 1, 1};
+			int cb[4] = {0, 0, 0, 0}, ce[4] = {1, 1, 1, 1};   // taps of the wave-row walk before the output's first row / up to its last row
 			int Pn = 0;
+			const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;   // LDS byte address of the item's column in ring slot 0
 			int slot = has ? base + top : 0;
 			slot = slot >= RR ? slot - RR : slot;
-			cb_u32 evmask = 0;   // rows (relative to the item's top) at which one of its outputs starts or ends
-#pragma unroll
-			for (int j = 0; j < 4; ++j)
-				if (erel[j] >= 0) evmask |= (1u << srel[j]) | (1u << erel[j]);
+			const cb_u32 evmask = sbit[0] | sbit[1] | sbit[2] | sbit[3] | ebit[0] | ebit[1] | ebit[2] | ebit[3];   // rows at which an output starts or ends
+			cb_u32 extbit = 1u << ext;   // (heights <= 2 A + 4 < 32)
+			asm volatile("" : "+v"(extbit));   // (opaque: stays one compare per row)
+			const cb_u32 Ebit = 1u << E;
 			cb_u32 mnext = ext > 0 ? (cb_u32)Ml[slot * TW + c] : 0u;
-			for (int i = 0; i < E; ++i) {
+			for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 1) {   // row i of the walk, as its (wave-uniform) bit 1 << i
 				const cb_u32 m = mnext;
 				const int n = (int)(m >> 8);
-				const float *p = (const float *)((const char *)(Vl + slot * SW + c + AH) - (m & 0xffu));
+				const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
 				slot = slot + 1 == RR ? 0 : slot + 1;
 				const cb_u32 mr = Ml[slot * TW + c];   // the next row's run travels while this row is summed
-				mnext = i + 1 < ext ? mr : 0u;
-				const bool anyev = __any((evmask >> i) & 1u);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
+				mnext = (ibit << 1) < extbit ? mr : 0u;   // (i + 1 < ext)
+				const bool anyev = __any(evmask & ibit);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
 				if (anyev) {
 #pragma unroll
 					for (int j = 0; j < 4; ++j) {
-						const bool st = i == srel[j];   // the output's first row: its chain starts from +0.0 here
+						const bool st = sbit[j] == ibit;   // the output's first row: its chain starts from +0.0 here
 						sum[j] = st ? 0.0f : sum[j];
 						cb[j] = st ? Pn : cb[j];
 					}
 				}
-				tile_taps<(A > 4)>(p, n, sum);
+				tile_taps<(A > 4)>(pa, n, sum);
 				Pn += n;
 				if (anyev) {
 #pragma unroll
 					for (int j = 0; j < 4; ++j) {
-						const bool en = i == erel[j];   // the output's last row
+						const bool en = ebit[j] == ibit;   // the output's last row
 						res[j] = en ? sum[j] : res[j];
-						cnt[j] = en ? Pn - cb[j] : cnt[j];
+						ce[j] = en ? Pn : ce[j];
 					}
 				}
 			}
 #pragma unroll
 			for (int j = 0; j < 4; ++j)
-				if (erel[j] >= 0) OUTl[(4 * g + j) * TW + c] = res[j] / (float)cnt[j];
+				if (outj[j]) OUTl[(4 * g + j) * TW + c] = res[j] / (float)(ce[j] - cb[j]);
+#ifndef MC_TILE_NO_SETPRIO
+			if (E >= 14) __builtin_amdgcn_s_setprio(0);
+#endif
 		}
 		TPROF(6);
 		__syncthreads();
@@ -441,6 +559,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 		// (no branch around the commit / the requests: on a path that skips them hipcc's wait-count model keeps the previous
 		// loads pending and protects their registers with full waits in the middle of the next step)
 		commit_rows(R, rrn, base, more ? TH : 0, tidc);   // relative row rrn = RR + k TH lives in slot (k TH) mod RR = base: the oldest rows go
+		if (MODE == 2) commit_tab(tidc);                  // ... and the next step's item table
 		TPROF(8);
 		// a wave stores whole rows through a descriptor that ends with the row: the words of a last unit that lie beyond the
 		// image (W not a multiple of 4) are dropped by the range check, rows beyond the region get an empty descriptor -- no branch
@@ -458,9 +577,11 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(ov[k].x), __float_as_uint(ov[k].y), __float_as_uint(ov[k].z), __float_as_uint(ov[k].w)}, rrow,
 			                                       lane < OPR ? (cb_u32)(y * W + x) * 4u : OOB, 0, VOL_AUX);
 		}
-		for (int q = tid; q < NG * NKEY; q += NTHREADS) GHl[q] = 0;
+		if (MODE != 2)
+			for (int q = tid; q < NG * NKEY; q += NTHREADS) GHl[q] = 0;
 		if (tid == 0) CTRl[0] = 0;
 		fetch_rows(R, rrn + TH, y0 + 2 * TH < ye ? TH : 0, tidc);
+		if (MODE == 2) fetch_tab(sidx + 2, tidc);
 #pragma unroll
 		for (int k = 0; k < NO; ++k) asm volatile("" :: "v"(ov[k]));   // (the stored values keep their registers until here)
 		base += TH;
@@ -481,26 +602,39 @@ extern "C" __attribute__((visibility("default"))) int mc_debug_tile_prof(unsigne
 }
 #endif
 
-template <int A, int TW, int TH, int NWAVES>
-static int cbca_tiles_launch(CbcaArgs P, bool nt, hipStream_t st)
+// regions: strips of TW columns x row ranges of a multiple of TH rows; enough of them for ~5 regions per XCD, a multiple of 8
+// where a nearby row split gives one
+static void tile_regions(int H, int W, int TW, int TH, int &gx, int &gy, int &rb)
+{
+	gx = (int)cdiv(W, TW);
+	const int steps = (int)cdiv(H, TH);
+	gy = std::max(1, std::min(steps, (int)cdiv(40, gx)));
+	for (int t = gy; t < gy + 8 && t <= steps; ++t)
+		if ((gx * t) % 8 == 0) { gy = t; break; }
+	rb = (int)cdiv(steps, gy) * TH;
+	gy = (int)cdiv(H, rb);
+}
+
+// the product's geometries (128 x 16 tiles for either arm class) share one plan layout
+constexpr int PLAN_TW = 128, PLAN_TH = 16;
+size_t cbca_plan_bytes(int D, int H, int W)
+{
+	int gx, gy, rb;
+	tile_regions(H, W, PLAN_TW, PLAN_TH, gx, gy, rb);
+	return (size_t)D * gx * gy * (rb / PLAN_TH) * TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES;
+}
+
+template <int A, int TW, int TH, int NWAVES, int MODE>
+static int cbca_tiles_launch_mode(CbcaArgs P, bool nt, hipStream_t st)
 {
 	using G = TileGeo<A, TW, TH>;
-	// regions: strips of TW columns x row ranges of a multiple of TH rows; enough of them for ~5 regions per XCD, a multiple
-	// of 8 where a nearby row split gives one
-	P.gx = (int)cdiv(P.W, TW);
-	const int steps = (int)cdiv(P.H, TH);
-	int gy = std::max(1, std::min(steps, (int)cdiv(40, P.gx)));
-	for (int t = gy; t < gy + 8 && t <= steps; ++t)
-		if ((P.gx * t) % 8 == 0) { gy = t; break; }
-	P.rb = (int)cdiv(steps, gy) * TH;
-	P.gy = (int)cdiv(P.H, P.rb);
 	const int64_t blocks = (int64_t)cdiv((int64_t)P.gx * P.gy, 8) * 8 * P.nd;
 	if (blocks > 0x7fffffff) {
 		set_error("cbca_tiles: %lld blocks", (long long)blocks);
 		return MC_EINVAL;
 	}
-	auto kern_nt = cbca_tile_kernel<A, TW, TH, NWAVES, true>;
-	auto kern = cbca_tile_kernel<A, TW, TH, NWAVES, false>;
+	auto kern_nt = cbca_tile_kernel<A, TW, TH, NWAVES, true, MODE>;
+	auto kern = cbca_tile_kernel<A, TW, TH, NWAVES, false, MODE>;
 	static bool attr_done = false;   // (idempotent; a race sets the same value twice)
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void *)kern_nt, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -512,8 +646,21 @@ static int cbca_tiles_launch(CbcaArgs P, bool nt, hipStream_t st)
 	return check_launch("cbca_tile");
 }
 
+template <int A, int TW, int TH, int NWAVES>
+static int cbca_tiles_launch(CbcaArgs P, bool nt, int plan_mode, hipStream_t st)
+{
+	tile_regions(P.H, P.W, TW, TH, P.gx, P.gy, P.rb);
+	P.spr = P.rb / TH;
+	if constexpr (TW == PLAN_TW && TH == PLAN_TH) {
+		static_assert(TileGeo<A, TW, TH>::ENT_BYTES == TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES, "one plan layout");
+		if (plan_mode == 1) return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 1>(P, nt, st);
+		if (plan_mode == 2) return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 2>(P, nt, st);
+	}
+	return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 0>(P, nt, st);   // (other geometries: no plan)
+}
+
 // arm_class 4: every arm <= 4 (L1 <= 5); 13: every arm <= 13 (L1 <= 14).  route >= 0 (the caller does not know the arms): the
-// launch stands down unless cbca_pack's route word equals it.
+// launch stands down unless cbca_pack's route word equals it.  cfg.plan / cfg.plan_mode: see the kernel.
 int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int route,
                hipStream_t st, const CbcaCfg &cfg)
 {
@@ -524,24 +671,26 @@ int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, 
 	P.vin = vin; P.vout = vout;
 	P.D = D; P.H = H; P.W = W; P.direction = direction;
 	P.d0 = d0; P.nd = nd;
-	P.rb = 0; P.gx = P.gy = 0;   // (regions: set by the launcher)
+	P.rb = 0; P.gx = P.gy = 0; P.spr = 0;   // (regions: set by the launcher)
 	P.flags = route >= 0 ? cs.flag : nullptr;
 	P.route = route;
+	const int pm = cfg.plan ? cfg.plan_mode : 0;
+	P.plan = pm ? cfg.plan : nullptr;
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
 	// cfg.variant selects the tile geometry (test / tuning hook; 0 = the product's choice)
 	if (arm_class <= 4) {
 		switch (cfg.variant) {
-		case 1: return cbca_tiles_launch<4, 128, 32, 8>(P, nt, st);
-		case 2: return cbca_tiles_launch<4, 128, 32, 4>(P, nt, st);
-		case 3: return cbca_tiles_launch<4, 256, 16, 8>(P, nt, st);
-		default: return cbca_tiles_launch<4, 128, 16, 4>(P, nt, st);
+		case 1: return cbca_tiles_launch<4, 128, 32, 8>(P, nt, pm, st);
+		case 2: return cbca_tiles_launch<4, 128, 32, 4>(P, nt, pm, st);
+		case 3: return cbca_tiles_launch<4, 256, 16, 8>(P, nt, pm, st);
+		default: return cbca_tiles_launch<4, 128, 16, 4>(P, nt, pm, st);
 		}
 	}
 	switch (cfg.variant) {
-	case 1: return cbca_tiles_launch<13, 128, 32, 8>(P, nt, st);
-	case 2: return cbca_tiles_launch<13, 128, 16, 4>(P, nt, st);
-	case 3: return cbca_tiles_launch<13, 64, 16, 4>(P, nt, st);
-	default: return cbca_tiles_launch<13, 128, 16, 8>(P, nt, st);
+	case 1: return cbca_tiles_launch<13, 128, 32, 8>(P, nt, pm, st);
+	case 2: return cbca_tiles_launch<13, 128, 16, 4>(P, nt, pm, st);
+	case 3: return cbca_tiles_launch<13, 64, 16, 4>(P, nt, pm, st);
+	default: return cbca_tiles_launch<13, 128, 16, 8>(P, nt, pm, st);
 	}
 }
 

@@ -31,6 +31,8 @@ struct CbcaCfg {
 	int nt = -1;       // volume cache policy: -1 auto, 0 default, 1 non-temporal
 	int d0 = 0, nd = 0;// planes [d0, d0 + nd) only (nd = 0: all)
 	int variant = 0;   // tile kernel: geometry variant (0 = the product's choice)
+	void *plan = nullptr;   // tile kernel: cbca_plan_bytes() bytes holding the item order of this pair and direction, or null
+	int plan_mode = 0; // 0 = no plan (every launch sorts its items), 1 = this launch sorts and writes the plan, 2 = this launch reads it
 };
 
 // ---- wave64 cross-lane primitives (DPP, no LDS round trip) -------------------

@@ -82,7 +82,7 @@ int mc_predict(const mc_params *p, const float *x0, const float *x1,
 ]]
 
 local lib = ffi.load('mcadcensus')
-local MC_ABI_VERSION = 5   -- include/mc_adcensus.h; tests/test_lua_shim.py checks this constant and every prototype above
+local MC_ABI_VERSION = 6   -- include/mc_adcensus.h; tests/test_lua_shim.py checks this constant and every prototype above
 assert(lib.mc_version() == MC_ABI_VERSION, ('libmcadcensus ABI version %d, this shim is written for %d'):format(
    lib.mc_version(), MC_ABI_VERSION))
 

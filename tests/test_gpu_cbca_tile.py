@@ -106,3 +106,36 @@ def test_tile_kernel_stands_down_when_an_arm_is_too_long(mc, oracle):
         out = torch.full((1, D, H, W), -7.0, device="cuda")
         mc.adcensus.cbca_cfg(dev(x0c), dev(x0c), dev(vl), out, -1, form=form)
         assert (out.cpu().numpy() == -7.0).all()
+
+
+PLAN_SHAPES = [(90, 300, 9), (41, 519, 6), (83, 64, 12), (140, 130, 3), (5, 7, 3), (17, 129, 9), (200, 1100, 4)]
+
+
+@pytest.mark.parametrize("H,W,D", PLAN_SHAPES)
+@pytest.mark.parametrize("mk,L1,tau1,forms", [("natural", 5, 0.13, (4, 6)), ("blocky", 5, 0.2, (4, 6)), ("smooth", 5, 0.13, (4, 6)),
+                                              ("natural", 14, 0.02, (5, 7)), ("blocky", 14, 0.2, (5, 7)), ("smooth", 14, 0.02, (5, 7)),
+                                              ("flat", 14, 1.0, (5, 7)), ("natural", 9, 0.05, (5, 7))])
+def test_tile_kernel_with_plan(mc, oracle, H, W, D, mk, L1, tau1, forms):
+    """what mc_predict does from the second aggregation pass of a direction on: the pass that sorts also writes every step's
+    item order (forms 4 / 5), later passes over OTHER volumes of the same pair read it (forms 6 / 7) -- each bit-identical to the
+    oracle; both directions (each with its own plan), a plane sub-range of a full plan"""
+    x0, x1 = pair(mk, H, W, D)
+    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
+    vl, vr = raw_volumes(D, H, W, seed=13)
+    v2l, v2r = raw_volumes(D, H, W, seed=14)
+    for direction, vol, vol2 in ((-1, vl, v2l), (1, vr, v2r)):
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, form=forms[0])
+        got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, vol, direction)
+        assert same_bits(got, want), diff_report(got, want, "tile kernel writing the plan, dir=%d" % direction)
+        for v in (vol2, vol):
+            out = torch.full((1, D, H, W), -7.0, device="cuda")
+            mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(v), out, direction, nt=(H + W) & 1, form=forms[1])
+            got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, v, direction)
+            assert same_bits(got, want), diff_report(got, want, "tile kernel reading the plan, dir=%d" % direction)
+        if D >= 6:
+            out = torch.full((1, D, H, W), -7.0, device="cuda")
+            mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol2), out, direction, d0=2, nd=3, form=forms[1])
+            got = out.cpu().numpy()[0]
+            want = oracle.cbca(x0c, x1c, vol2, direction)
+            assert same_bits(got[2:5], want[2:5]) and (got[:2] == -7.0).all() and (got[5:] == -7.0).all()
