@@ -33,6 +33,8 @@ struct CbcaArgs {
 	int d0, nd;                   // planes [d0, d0 + nd) of the volume are processed by this launch
 	void *plan;                   // tile kernel: the pair's item order per (plane, region, step), written by one launch and read by the others
 	int spr;                      // ... steps per region
+	size_t plan_m, plan_ud;       // ... byte offsets of the combined runs / vertical arms behind the tables
+	int wp;                       // ... their row length in pixels
 };
 
 

@@ -18,8 +18,15 @@
 // committed to the ring after it: every row of the plane is read once per strip and memory latency hides behind the
 // additions.  A wave runs at the pace of its tallest item and longest runs, and real scenes mix 3 x 3 supports with flat
 // regions of (2 L1 - 1)^2 taps: the step's items are SORTED by height (counting sort in LDS, a few instructions per item)
-// and the waves of the block pull 64-item chunks, tallest first, from a shared counter.  Results go to an LDS tile and
-// leave as full rows.
+// and the waves of the block pull 64-item chunks, tallest first, from a shared counter.  Two classes need no walk at all:
+// items of four minimal 3 x 3 supports (six rows x three values, unrolled) and items whose four outputs are all three rows
+// tall (row r of the item's six feeds outputs max(0, r - 2) .. min(3, r): runs are looked up, nothing else).  Results go
+// to an LDS tile and leave as full rows.
+//
+// None of that bookkeeping depends on the volume: mc_predict aggregates a pair 2 + 16 times per direction (main.lua:998-1001,
+// 1033-1039) and keeps the first pass's work in a PLAN -- per (plane, region, step) the sorted item table and the class
+// counts, per voxel the combined run (2 bytes) and vertical arms (1 byte) as committed to the ring -- which the other passes
+// read a step ahead with the rows (3.5 bytes per voxel of extra traffic for a third of the instructions).
 #include "cbca_common.h"
 #include <algorithm>
 #include <type_traits>
@@ -118,6 +125,57 @@ __device__ __forceinline__ void tile_taps3(unsigned pa, int n, float &a, float &
 	if (LONG) asm volatile(MC_TAPS_27(3) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), [s2] "+v"(c), MC_TAPS_TMPS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
 	else asm volatile(MC_TAPS_9(3) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), [s2] "+v"(c), MC_TAPS_TMPS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
 }
+// ... with the first nine values already in registers (requested a row ahead by the caller, who also waits for them): the
+// plan-reading instance, which has the registers for it
+#define MC_TAPS_9P(K) "s_mov_b64 %[sv], exec\n" \
+	MC_TAP(K, 0, v0) MC_TAP(K, 1, v1) MC_TAP(K, 2, v2) MC_EXIT MC_TAP(K, 3, v3) MC_TAP(K, 4, v4) MC_EXIT \
+	MC_TAP(K, 5, v5) MC_TAP(K, 6, v6) MC_TAP(K, 7, v7) MC_TAP(K, 8, v8)
+#define MC_TAPS_27P(K) MC_TAPS_9P(K) MC_EXIT MC_LOAD9(36) "s_waitcnt lgkmcnt(0)\n" \
+	MC_TAP(K, 9, v0) MC_TAP(K, 10, v1) MC_TAP(K, 11, v2) MC_TAP(K, 12, v3) MC_EXIT MC_TAP(K, 13, v4) MC_TAP(K, 14, v5) MC_TAP(K, 15, v6) MC_TAP(K, 16, v7) \
+	MC_TAP(K, 17, v8) MC_EXIT MC_LOAD9(72) "s_waitcnt lgkmcnt(0)\n" \
+	MC_TAP(K, 18, v0) MC_TAP(K, 19, v1) MC_TAP(K, 20, v2) MC_TAP(K, 21, v3) MC_TAP(K, 22, v4) MC_EXIT MC_TAP(K, 23, v5) MC_TAP(K, 24, v6) MC_TAP(K, 25, v7) \
+	MC_TAP(K, 26, v8)
+#define MC_TAPS_VALS [v0] "+v"(v[0]), [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3]), [v4] "+v"(v[4]), [v5] "+v"(v[5]), [v6] "+v"(v[6]), [v7] "+v"(v[7]), \
+	[v8] "+v"(v[8]), [sv] "=&s"(sv)
+typedef const float __attribute__((address_space(3))) *lds_cfp;
+__device__ __forceinline__ void tile_load9(float (&v)[9], unsigned pa)
+{
+	const lds_cfp p = (lds_cfp)pa;
+#pragma unroll
+	for (int t = 0; t < 9; ++t) v[t] = p[t];
+}
+template <bool LONG>
+__device__ __forceinline__ void tile_taps_p(float (&v)[9], unsigned pa, int n, float (&sum)[4])
+{
+	unsigned long long sv;
+	if (LONG)
+		asm volatile(MC_TAPS_27P(4) MC_TAPS_END : [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3]), MC_TAPS_VALS
+		             : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+	else
+		asm volatile(MC_TAPS_9P(4) MC_TAPS_END : [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3]), MC_TAPS_VALS
+		             : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+}
+template <bool LONG>
+__device__ __forceinline__ void tile_taps1_p(float (&v)[9], unsigned pa, int n, float &a)
+{
+	unsigned long long sv;
+	if (LONG) asm volatile(MC_TAPS_27P(1) MC_TAPS_END : [s0] "+v"(a), MC_TAPS_VALS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+	else asm volatile(MC_TAPS_9P(1) MC_TAPS_END : [s0] "+v"(a), MC_TAPS_VALS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+}
+template <bool LONG>
+__device__ __forceinline__ void tile_taps2_p(float (&v)[9], unsigned pa, int n, float &a, float &b)
+{
+	unsigned long long sv;
+	if (LONG) asm volatile(MC_TAPS_27P(2) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), MC_TAPS_VALS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+	else asm volatile(MC_TAPS_9P(2) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), MC_TAPS_VALS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+}
+template <bool LONG>
+__device__ __forceinline__ void tile_taps3_p(float (&v)[9], unsigned pa, int n, float &a, float &b, float &c)
+{
+	unsigned long long sv;
+	if (LONG) asm volatile(MC_TAPS_27P(3) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), [s2] "+v"(c), MC_TAPS_VALS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+	else asm volatile(MC_TAPS_9P(3) MC_TAPS_END : [s0] "+v"(a), [s1] "+v"(b), [s2] "+v"(c), MC_TAPS_VALS : [n] "v"(n), [p] "v"(pa) : "vcc", "memory");
+}
 #undef MC_TAP
 #undef MC_LOAD9
 #undef MC_EXIT
@@ -127,8 +185,9 @@ __device__ __forceinline__ void tile_taps3(unsigned pa, int n, float &a, float &
 // P.gx x P.gy regions of TW columns x P.rb rows (a multiple of TH); a block takes one (region, plane).
 // The order of a step's items depends on the pair's arms and the plane only -- not on the volume -- and a pair is aggregated many
 // times over (main.lua:998-1001, 1033-1039: 2 + 16 iterations per direction on Middlebury).  MODE 1: the launch sorts and also
-// writes every step's table + (nz, nfast) to P.plan; MODE 2: it reads them a step ahead, together with the rows, and has no sort
-// pass and two barriers per step instead of four; MODE 0: no plan (adcensus.cbca called on its own).
+// writes every step's table + class counts and its own rows' combined runs / vertical arms to P.plan; MODE 2: it reads them a
+// step ahead, together with the volume's rows -- no packed lengths, no sort pass, two barriers per step instead of four;
+// MODE 0: no plan (adcensus.cbca called on its own).
 template <int A, int TW, int TH, int NWAVES, bool NT, int MODE>
 __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ? 4 : 1)) cbca_tile_kernel(const CbcaArgs P)
 {
@@ -137,6 +196,11 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	constexpr int NTHREADS = 64 * NWAVES;
 	constexpr int VOL_AUX = NT ? 2 : 0;
 	constexpr int NG = G::NG;
+#ifdef MC_TILE_NO_PIPE
+	constexpr bool PIPE = false;
+#else
+	constexpr bool PIPE = MODE == 2;   // values requested a row ahead: 10 more registers, which only the plan-reading instance has
+#endif
 	static_assert(TH % 4 == 0 && TW % 64 == 0 && TW <= 256 && TH / 4 <= 256 && 2 * A + 5 < NKEY && A <= 15 && NG % NWAVES == 0, "tile geometry");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	float *__restrict__ Vl = (float *)smem;
@@ -179,26 +243,39 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	const __amdgpu_buffer_rsrc_t rplan = __builtin_amdgcn_make_buffer_rsrc(
 		MODE ? (void *)((char *)P.plan + ((size_t)d * (size_t)(P.gx * P.gy) + (size_t)region) * (size_t)P.spr * ENT) : nullptr, 0, MODE ? P.spr * ENT : 0, 0x00020000);
 
+	// ... and behind the tables, per plane, the combined runs (2 bytes per pixel) and vertical arms (1 byte) exactly as the
+	// first pass committed them to its ring: rows of Wp = W rounded up to 4 pixels
+	const int Wp = P.wp;
+	const __amdgpu_buffer_rsrc_t rpm = __builtin_amdgcn_make_buffer_rsrc(MODE ? (void *)((char *)P.plan + P.plan_m + (size_t)d * H * Wp * 2) : nullptr, 0,
+	                                                                     MODE ? H * Wp * 2 : 0, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rpu = __builtin_amdgcn_make_buffer_rsrc(MODE ? (void *)((char *)P.plan + P.plan_ud + (size_t)d * H * Wp) : nullptr, 0,
+	                                                                     MODE ? H * Wp : 0, 0x00020000);
+
 	for (int q = tid; q < NG * NKEY; q += NTHREADS) GHl[q] = 0;
 	if (tid == 0) CTRl[0] = 0;
 
 	// ---- rows in flight: TH rows of values (all staged columns) and packed lengths (output columns) per thread -------
 	constexpr int UPR = SW / 4, APR = TW / 4;   // 4-column units per row
+	// (index arithmetic of the requests / commits: 24-bit multiplies are full rate, 32-bit ones a quarter)
+#define TMUL(a, b) __mul24((a), (b))
+#define TQDIV(q) ((int)(__umul24((cb_u32)(q), UPR_RCP) >> 20))
+	constexpr cb_u32 UPR_RCP = ((1u << 20) + UPR - 1) / UPR;
+	static_assert([] { for (cb_u32 q = 0; q < 4096; ++q) if (((q * UPR_RCP) >> 20) != q / UPR) return false; return true; }(), "q / UPR by multiplication");
 	constexpr int NV = (TH * UPR + NTHREADS - 1) / NTHREADS, NA = (TH * APR + NTHREADS - 1) / NTHREADS;
-	struct Rows { cb_u4 v[NV], a[NA], b[NA]; };
+	struct Rows { cb_u4 v[NV], a[NA], b[NA]; cb_u2 m[NA]; cb_u32 ud[NA]; };   // (a, b: MODE 0 / 1; m, ud: MODE 2)
 	const int ylast = min(H, ye + A);   // rows from here on are never needed
 	// relative rows rr0 .. rr0 + nrows - 1 (relative row rr = image row yr0 + rr) -> registers; rows outside the image: zeros
 	auto fetch_rows = [&](Rows &R, int rr0, int nrows, int tid) {
 #pragma unroll
 		for (int k = 0; k < NV; ++k) {
 			const int q = tid + k * NTHREADS;
-			const int r = q / UPR, u = q - r * UPR;
+			const int r = TQDIV(q), u = q - r * UPR;
 			const int y = yr0 + rr0 + r, x = sx0 + 4 * u;
 			const bool rok = r < nrows && y >= 0 && y < ylast;
 			// one 16-byte load wherever the unit starts: columns left of the image read the end of the row above (or, before the
 			// plane, nothing), columns right of it the start of the row below (or, behind the plane, nothing) -- no run ever
 			// includes a column outside the image, so what those words hold is never an operand
-			R.v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)(y * W + x) * 4u : OOB, 0, VOL_AUX);
+			R.v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, rok ? (cb_u32)(TMUL(y, W) + x) * 4u : OOB, 0, VOL_AUX);
 		}
 #pragma unroll
 		for (int k = 0; k < NA; ++k) {
@@ -206,10 +283,17 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			const int r = q / APR, u = q - r * APR;
 			const int y = yr0 + rr0 + r, x = tx0 + 4 * u;
 			const bool rok = r < nrows && y >= 0 && y < ylast;
-			const int base = y * W + x;
-			// the padded scratch makes any in-row start readable; columns outside the image / the shifted range are masked at commit
-			R.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
-			R.b[k] = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
+			if constexpr (MODE == 2) {   // the combined runs and vertical arms as the first pass committed them
+				const bool in = rok && x < Wp;
+				const cb_u32 pix = (cb_u32)(TMUL(y, Wp) + x);
+				R.m[k] = __builtin_amdgcn_raw_buffer_load_b64(rpm, in ? pix * 2u : OOB, 0, 0);
+				R.ud[k] = __builtin_amdgcn_raw_buffer_load_b32(rpu, in ? pix : OOB, 0, 0);
+			} else {
+				const int base = TMUL(y, W) + x;
+				// the padded scratch makes any in-row start readable; columns outside the image / the shifted range are masked at commit
+				R.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
+				R.b[k] = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
+			}
 		}
 	};
 	// ... -> ring slots (slot0 = ring slot of relative row rr0)
@@ -217,11 +301,11 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 #pragma unroll
 		for (int k = 0; k < NV; ++k) {
 			const int q = tid + k * NTHREADS;
-			const int r = q / UPR, u = q - r * UPR;
+			const int r = TQDIV(q), u = q - r * UPR;
 			if (r >= nrows) continue;
 			int slot = slot0 + r;
 			slot = slot >= RR ? slot - RR : slot;
-			*(cb_u4 *)(Vl + slot * SW + 4 * u) = R.v[k];
+			*(cb_u4 *)(Vl + TMUL(slot, SW) + 4 * u) = R.v[k];
 		}
 #pragma unroll
 		for (int k = 0; k < NA; ++k) {
@@ -231,18 +315,34 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			int slot = slot0 + r;
 			slot = slot >= RR ? slot - RR : slot;
 			const int y = yr0 + rr0 + r, x = tx0 + 4 * u;
-			const cb_u32 spanr = (y >= 0 && y < H) ? span : 0u;   // pixel exists, partner inside the image (adcensus.cu:353)
-			const cb_u32 mm[4] = {bytemin4(R.a[k].x, R.b[k].x), bytemin4(R.a[k].y, R.b[k].y), bytemin4(R.a[k].z, R.b[k].z), bytemin4(R.a[k].w, R.b[k].w)};
-			cb_u32 run[4], ud[4];
+			const bool yin = y >= 0 && y < ylast;   // (rows from ylast on are never looked at: like rows outside the image, no outputs, no runs)
+			cb_u2 m4;
+			cb_u32 ud4;
+			if constexpr (MODE == 2) {
+				const bool in = yin && x < Wp;
+				m4 = in ? R.m[k] : cb_u2{0u, 0u};
+				ud4 = in ? R.ud[k] : 0xffffffffu;
+			} else {
+				const cb_u32 spanr = yin ? span : 0u;   // pixel exists, partner inside the image (adcensus.cu:353)
+				const cb_u32 mm[4] = {bytemin4(R.a[k].x, R.b[k].x), bytemin4(R.a[k].y, R.b[k].y), bytemin4(R.a[k].z, R.b[k].z), bytemin4(R.a[k].w, R.b[k].w)};
+				cb_u32 run[4], ud[4];
 #pragma unroll
-			for (int t = 0; t < 4; ++t) {
-				const bool ok = (cb_u32)(x + t - lo) < spanr;
-				const cb_u32 l = mm[t] & 0xffu, rr = (mm[t] >> 8) & 0xffu;
-				run[t] = ok ? ((4u * l) | ((l + rr + 1u) << 8)) : 0u;
-				ud[t] = ok ? (((mm[t] >> 16) & 15u) | ((mm[t] >> 20) & 0xf0u)) : 0xffu;
+				for (int t = 0; t < 4; ++t) {
+					const bool ok = (cb_u32)(x + t - lo) < spanr;
+					const cb_u32 l = mm[t] & 0xffu, rr = (mm[t] >> 8) & 0xffu;
+					run[t] = ok ? ((4u * l) | ((l + rr + 1u) << 8)) : 0u;
+					ud[t] = ok ? (((mm[t] >> 16) & 15u) | ((mm[t] >> 20) & 0xf0u)) : 0xffu;
+				}
+				m4 = cb_u2{run[0] | (run[1] << 16), run[2] | (run[3] << 16)};
+				ud4 = ud[0] | (ud[1] << 8) | (ud[2] << 16) | (ud[3] << 24);
+				if constexpr (MODE == 1) {   // the block's own rows -> plan (halo rows belong to the regions above / below)
+					const bool own = y >= ys && y < ye && x < Wp;
+					__builtin_amdgcn_raw_buffer_store_b64(m4, rpm, own ? (cb_u32)(y * Wp + x) * 2u : OOB, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(ud4, rpu, own ? (cb_u32)(y * Wp + x) : OOB, 0, 0);
+				}
 			}
-			*(cb_u2 *)(Ml + slot * TW + 4 * u) = cb_u2{run[0] | (run[1] << 16), run[2] | (run[3] << 16)};
-			*(cb_u32 *)(UDl + slot * TW + 4 * u) = ud[0] | (ud[1] << 8) | (ud[2] << 16) | (ud[3] << 24);
+			*(cb_u2 *)(Ml + slot * TW + 4 * u) = m4;
+			*(cb_u32 *)(UDl + slot * TW + 4 * u) = ud4;
 		}
 	};
 
@@ -464,18 +564,42 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 				const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;
 				float fs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 				int nr[6];
+				if constexpr (PIPE) {   // the six run words first, then every row's values requested while the row before it is summed
+					cb_u32 pa[6];
 #pragma unroll
-				for (int r = 0; r < 6; ++r) {
-					const cb_u32 m = has ? (cb_u32)Ml[slot * TW + c] : 0u;
-					nr[r] = (int)(m >> 8);
-					const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
-					slot = slot + 1 == RR ? 0 : slot + 1;
-					if (r == 0) tile_taps1<(A > 4)>(pa, nr[r], fs[0]);
-					else if (r == 1) tile_taps2<(A > 4)>(pa, nr[r], fs[0], fs[1]);
-					else if (r == 2) tile_taps3<(A > 4)>(pa, nr[r], fs[0], fs[1], fs[2]);
-					else if (r == 3) tile_taps3<(A > 4)>(pa, nr[r], fs[1], fs[2], fs[3]);
-					else if (r == 4) tile_taps2<(A > 4)>(pa, nr[r], fs[2], fs[3]);
-					else tile_taps1<(A > 4)>(pa, nr[r], fs[3]);
+					for (int r = 0; r < 6; ++r) {
+						const cb_u32 m = has ? (cb_u32)Ml[slot * TW + c] : 0u;
+						nr[r] = (int)(m >> 8);
+						pa[r] = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
+						slot = slot + 1 == RR ? 0 : slot + 1;
+					}
+					float va[9], vb[9];
+					tile_load9(va, pa[0]);
+					tile_load9(vb, pa[1]);
+					tile_taps1_p<(A > 4)>(va, pa[0], nr[0], fs[0]);
+					tile_load9(va, pa[2]);
+					tile_taps2_p<(A > 4)>(vb, pa[1], nr[1], fs[0], fs[1]);
+					tile_load9(vb, pa[3]);
+					tile_taps3_p<(A > 4)>(va, pa[2], nr[2], fs[0], fs[1], fs[2]);
+					tile_load9(va, pa[4]);
+					tile_taps3_p<(A > 4)>(vb, pa[3], nr[3], fs[1], fs[2], fs[3]);
+					tile_load9(vb, pa[5]);
+					tile_taps2_p<(A > 4)>(va, pa[4], nr[4], fs[2], fs[3]);
+					tile_taps1_p<(A > 4)>(vb, pa[5], nr[5], fs[3]);
+				} else {
+#pragma unroll
+					for (int r = 0; r < 6; ++r) {
+						const cb_u32 m = has ? (cb_u32)Ml[slot * TW + c] : 0u;
+						nr[r] = (int)(m >> 8);
+						const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
+						slot = slot + 1 == RR ? 0 : slot + 1;
+						if (r == 0) tile_taps1<(A > 4)>(pa, nr[r], fs[0]);
+						else if (r == 1) tile_taps2<(A > 4)>(pa, nr[r], fs[0], fs[1]);
+						else if (r == 2) tile_taps3<(A > 4)>(pa, nr[r], fs[0], fs[1], fs[2]);
+						else if (r == 3) tile_taps3<(A > 4)>(pa, nr[r], fs[1], fs[2], fs[3]);
+						else if (r == 4) tile_taps2<(A > 4)>(pa, nr[r], fs[2], fs[3]);
+						else tile_taps1<(A > 4)>(pa, nr[r], fs[3]);
+					}
 				}
 #pragma unroll
 				for (int j = 0; j < 4; ++j)
@@ -511,31 +635,74 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			cb_u32 extbit = 1u << ext;   // (heights <= 2 A + 4 < 32)
 			asm volatile("" : "+v"(extbit));   // (opaque: stays one compare per row)
 			const cb_u32 Ebit = 1u << E;
-			cb_u32 mnext = ext > 0 ? (cb_u32)Ml[slot * TW + c] : 0u;
-			for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 1) {   // row i of the walk, as its (wave-uniform) bit 1 << i
-				const cb_u32 m = mnext;
-				const int n = (int)(m >> 8);
-				const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
-				slot = slot + 1 == RR ? 0 : slot + 1;
-				const cb_u32 mr = Ml[slot * TW + c];   // the next row's run travels while this row is summed
-				mnext = (ibit << 1) < extbit ? mr : 0u;   // (i + 1 < ext)
-				const bool anyev = __any(evmask & ibit);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
-				if (anyev) {
+			if constexpr (PIPE) {
+				// the walk, two rows in flight: while row i is summed the values of row i + 1 are on their way (requested through the
+				// run word that was fetched during row i - 1) and so is the run word of row i + 2
+				int slotC = slot, slotN = slot + 1 == RR ? 0 : slot + 1;
+				cb_u32 mC = ext > 0 ? (cb_u32)Ml[slotC * TW + c] : 0u;
+				cb_u32 mN = 2u < extbit ? (cb_u32)Ml[slotN * TW + c] : 0u;   // (1 < ext)
+				float va[9], vb[9];
+				tile_load9(va, __umul24((cb_u32)slotC, (cb_u32)(SW * 4)) + cv - (mC & 0xffu));
+				auto walk_row = [&](float (&cur)[9], float (&nxt)[9], cb_u32 ibit) {
+					const cb_u32 paN = __umul24((cb_u32)slotN, (cb_u32)(SW * 4)) + cv - (mN & 0xffu);
+					tile_load9(nxt, paN);
+					const int slotNN = slotN + 1 == RR ? 0 : slotN + 1;
+					const cb_u32 mr = Ml[slotNN * TW + c];
+					const cb_u32 mNN = (ibit << 2) < extbit ? mr : 0u;   // (i + 2 < ext)
+					const int n = (int)(mC >> 8);
+					const cb_u32 pa = __umul24((cb_u32)slotC, (cb_u32)(SW * 4)) + cv - (mC & 0xffu);
+					const bool anyev = __any(evmask & ibit);
+					if (anyev) {
 #pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						const bool st = sbit[j] == ibit;   // the output's first row: its chain starts from +0.0 here
-						sum[j] = st ? 0.0f : sum[j];
-						cb[j] = st ? Pn : cb[j];
+						for (int j = 0; j < 4; ++j) {
+							const bool st = sbit[j] == ibit;
+							sum[j] = st ? 0.0f : sum[j];
+							cb[j] = st ? Pn : cb[j];
+						}
 					}
-				}
-				tile_taps<(A > 4)>(pa, n, sum);
-				Pn += n;
-				if (anyev) {
+					tile_taps_p<(A > 4)>(cur, pa, n, sum);
+					Pn += n;
+					if (anyev) {
 #pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						const bool en = ebit[j] == ibit;   // the output's last row
-						res[j] = en ? sum[j] : res[j];
-						ce[j] = en ? Pn : ce[j];
+						for (int j = 0; j < 4; ++j) {
+							const bool en = ebit[j] == ibit;
+							res[j] = en ? sum[j] : res[j];
+							ce[j] = en ? Pn : ce[j];
+						}
+					}
+					slotC = slotN; mC = mN; slotN = slotNN; mN = mNN;
+				};
+				for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 2) {
+					walk_row(va, vb, ibit);
+					if ((ibit << 1) < Ebit) walk_row(vb, va, ibit << 1);
+				}
+			} else {
+				cb_u32 mnext = ext > 0 ? (cb_u32)Ml[slot * TW + c] : 0u;
+				for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 1) {   // row i of the walk, as its (wave-uniform) bit 1 << i
+					const cb_u32 m = mnext;
+					const int n = (int)(m >> 8);
+					const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
+					slot = slot + 1 == RR ? 0 : slot + 1;
+					const cb_u32 mr = Ml[slot * TW + c];   // the next row's run travels while this row is summed
+					mnext = (ibit << 1) < extbit ? mr : 0u;   // (i + 1 < ext)
+					const bool anyev = __any(evmask & ibit);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
+					if (anyev) {
+#pragma unroll
+						for (int j = 0; j < 4; ++j) {
+							const bool st = sbit[j] == ibit;   // the output's first row: its chain starts from +0.0 here
+							sum[j] = st ? 0.0f : sum[j];
+							cb[j] = st ? Pn : cb[j];
+						}
+					}
+					tile_taps<(A > 4)>(pa, n, sum);
+					Pn += n;
+					if (anyev) {
+#pragma unroll
+						for (int j = 0; j < 4; ++j) {
+							const bool en = ebit[j] == ibit;   // the output's last row
+							res[j] = en ? sum[j] : res[j];
+							ce[j] = en ? Pn : ce[j];
+						}
 					}
 				}
 			}
@@ -617,12 +784,20 @@ static void tile_regions(int H, int W, int TW, int TH, int &gx, int &gy, int &rb
 
 // the product's geometries (128 x 16 tiles for either arm class) share one plan layout
 constexpr int PLAN_TW = 128, PLAN_TH = 16;
-size_t cbca_plan_bytes(int D, int H, int W)
+// [item tables: D x regions x steps per region entries | combined runs (D, H, Wp) u16 | vertical arms (D, H, Wp) u8]
+struct PlanLayout { size_t m, ud, total; int wp; };
+static PlanLayout plan_layout(int D, int H, int W)
 {
 	int gx, gy, rb;
 	tile_regions(H, W, PLAN_TW, PLAN_TH, gx, gy, rb);
-	return (size_t)D * gx * gy * (rb / PLAN_TH) * TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES;
+	PlanLayout L;
+	L.wp = (W + 3) / 4 * 4;
+	L.m = ((size_t)D * gx * gy * (rb / PLAN_TH) * TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES + 255) / 256 * 256;
+	L.ud = L.m + ((size_t)D * H * L.wp * 2 + 255) / 256 * 256;
+	L.total = L.ud + (size_t)D * H * L.wp;
+	return L;
 }
+size_t cbca_plan_bytes(int D, int H, int W) { return plan_layout(D, H, W).total; }
 
 template <int A, int TW, int TH, int NWAVES, int MODE>
 static int cbca_tiles_launch_mode(CbcaArgs P, bool nt, hipStream_t st)
@@ -651,6 +826,8 @@ static int cbca_tiles_launch(CbcaArgs P, bool nt, int plan_mode, hipStream_t st)
 {
 	tile_regions(P.H, P.W, TW, TH, P.gx, P.gy, P.rb);
 	P.spr = P.rb / TH;
+	const PlanLayout L = plan_layout(P.D, P.H, P.W);
+	P.plan_m = L.m; P.plan_ud = L.ud; P.wp = L.wp;
 	if constexpr (TW == PLAN_TW && TH == PLAN_TH) {
 		static_assert(TileGeo<A, TW, TH>::ENT_BYTES == TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES, "one plan layout");
 		if (plan_mode == 1) return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 1>(P, nt, st);

@@ -61,6 +61,8 @@ for d in ds:
                     evrows = np.zeros(e, bool)
                     evrows[s0[g, :, c] - t] = True; evrows[e0[g, :, c] - t] = True
                     reg3 = (not is_mini) and mini[g, c] and e == 6
+                    full = (U.reshape(TH // 4, 4, TW)[g, :, c] == A).all() and (Dn.reshape(TH // 4, 4, TW)[g, :, c] == A).all()
+                    acc("n_items", 1); acc("n_items_full", int(full)); acc("n_items_tall", int(e >= 20))
                     key = 1 if is_mini else (2 if (reg3 and REG3) else e + 1)
                     items.append((key, runs, evrows, sum(n[s0[g, j, c]:e0[g, j, c] + 1, tx + c].sum() for j in range(4)), reg3))
             if not items: continue
