@@ -42,10 +42,16 @@ __device__ unsigned long long tile_prof[4096];
 
 namespace {
 
-template <int A, int TW, int TH>
+template <int A, int TW, int TH, int MODE = 0>
 struct TileGeo {
 	static constexpr int AH = (A + 3) & ~3;           // horizontal halo, a multiple of 4 columns (16-byte rows)
-	static constexpr int SW = TW + 2 * AH;            // staged columns
+#ifndef MC_TILE_SWPAD
+#define MC_TILE_SWPAD 4   // (measured: 0 / 4 -> 2.885 / 2.835 ms per launch; 12 no longer fits three blocks per CU)
+#endif
+	// staged columns; the long-arm instance pads its rows so that the row stride is not a multiple of the 32 LDS banks: lanes of a chunk
+	// read the same columns at different rows (runs that start at the same image edge), which a stride of 160 words puts into one bank
+	// (only the plan-reading instance, which has no sort histogram in LDS, has the bytes for it: three blocks per CU)
+	static constexpr int SW = TW + 2 * AH + ((A > 4 && MODE == 2) ? MC_TILE_SWPAD : 0);
 	static constexpr int RR = TH + 2 * A;             // ring rows: the window of one step
 	static constexpr int NI = TW * (TH / 4);          // items of a step: column x 4 rows
 	static constexpr int NG = NI / 64;                // groups of 64 consecutive items (one wave's worth)
@@ -56,7 +62,7 @@ struct TileGeo {
 	static constexpr int OUT_BYTES = TH * TW * 4;
 	static constexpr int TAB_BYTES = NI * 2 + 16;          // sorted items, then (nz, nfast) of the step: one plan entry
 	static constexpr int ENT_BYTES = TAB_BYTES;            // plan entry of one (plane, region, step)
-	static constexpr int MISC_BYTES = NG * NKEY * 4 + 16;   // items per group and key; chunk counter
+	static constexpr int MISC_BYTES = (MODE == 2 ? 0 : NG * NKEY * 4) + 16;   // items per group and key (sort); chunk counter
 	static constexpr int LDS_BYTES = V_BYTES + M_BYTES + UD_BYTES + OUT_BYTES + TAB_BYTES + MISC_BYTES;
 };
 
@@ -191,11 +197,16 @@ __device__ __forceinline__ void tile_taps3_p(float (&v)[9], unsigned pa, int n, 
 template <int A, int TW, int TH, int NWAVES, bool NT, int MODE>
 __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ? 4 : 1)) cbca_tile_kernel(const CbcaArgs P)
 {
-	using G = TileGeo<A, TW, TH>;
+	using G = TileGeo<A, TW, TH, MODE>;
 	constexpr int AH = G::AH, SW = G::SW, RR = G::RR, NI = G::NI, NKEY = G::NKEY;
 	constexpr int NTHREADS = 64 * NWAVES;
 	constexpr int VOL_AUX = NT ? 2 : 0;
 	constexpr int NG = G::NG;
+	constexpr int KT_ROWS = 14;        // "tall": items of this many rows and more
+#ifndef MC_TILE_NSPLIT
+#define MC_TILE_NSPLIT 64   // (measured: 0 / 64 / 128 / 256 -> 2.90 / 2.86 / 2.89 / 3.08 ms per launch on the realistic pair)
+#endif
+	constexpr int NSPLIT_MAX = MC_TILE_NSPLIT;   // a step's tall items are taken apart into single outputs if there are at most this many
 #ifdef MC_TILE_NO_PIPE
 	constexpr bool PIPE = false;
 #else
@@ -209,7 +220,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	float *__restrict__ OUTl = (float *)(smem + G::V_BYTES + G::M_BYTES + G::UD_BYTES);
 	unsigned short *__restrict__ TABl = (unsigned short *)(smem + G::V_BYTES + G::M_BYTES + G::UD_BYTES + G::OUT_BYTES);
 	cb_u32 *__restrict__ GHl = (cb_u32 *)(smem + G::V_BYTES + G::M_BYTES + G::UD_BYTES + G::OUT_BYTES + G::TAB_BYTES);   // [group][key]
-	cb_u32 *__restrict__ CTRl = GHl + NG * NKEY;   // [0] next chunk
+	cb_u32 *__restrict__ CTRl = GHl + (MODE == 2 ? 0 : NG * NKEY);   // [0] next chunk
 
 	if (!cbca_gate(P.flags, P.route)) return;   // (the pair's arms call for another kernel)
 	const int tid0 = threadIdx.x;
@@ -251,7 +262,8 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	const __amdgpu_buffer_rsrc_t rpu = __builtin_amdgcn_make_buffer_rsrc(MODE ? (void *)((char *)P.plan + P.plan_ud + (size_t)d * H * Wp) : nullptr, 0,
 	                                                                     MODE ? H * Wp : 0, 0x00020000);
 
-	for (int q = tid; q < NG * NKEY; q += NTHREADS) GHl[q] = 0;
+	if (MODE != 2)
+		for (int q = tid; q < NG * NKEY; q += NTHREADS) GHl[q] = 0;
 	if (tid == 0) CTRl[0] = 0;
 
 	// ---- rows in flight: TH rows of values (all staged columns) and packed lengths (output columns) per thread -------
@@ -417,7 +429,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			}
 			return udall;
 		};
-		int nz, nfast, ngen;   // items [0, ngen): general walk, [ngen, nfast): three-row class, [nfast, nz): four 3 x 3 supports
+		int nz, nfast, ngen, ntall;   // items [0, ngen): general walk (the first ntall of them KT_ROWS rows or taller), [ngen, nfast): three-row class, [nfast, nz): four 3 x 3 supports
 		if constexpr (MODE != 2) {
 			// ---- items sorted by height (tallest first): counting sort ------------------------------------------------
 			// key of an item: 0 = nothing to compute, 1 = its four supports are all the minimal 3 x 3, 2 = its four outputs all reach
@@ -495,6 +507,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 				nz = NI - __builtin_amdgcn_readlane((int)total, 0);           // items with at least one output to compute
 				nfast = nz - __builtin_amdgcn_readlane((int)total, 1);        // ... of which the last ones are four 3 x 3 supports each
 				ngen = nfast - __builtin_amdgcn_readlane((int)total, 2);      // ... preceded by the three-row class
+				ntall = (int)(all - (cb_u32)__builtin_amdgcn_readlane((int)sc, KT_ROWS));   // keys > KT_ROWS: heights >= KT_ROWS
 #pragma unroll
 				for (int k = 0; k < IPT; ++k) posbase[k] = above + pre[k];
 			}
@@ -504,7 +517,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 				const int c = i % TW, g = i / TW;
 				const cb_u32 key = keyrank[k] & 0xffu, rank = keyrank[k] >> 8;
 				const cb_u32 first = (cb_u32)__builtin_amdgcn_ds_bpermute((int)(key * 4u), (int)posbase[k]);
-				TABl[first + rank] = (unsigned short)(c | (g << 8));
+				TABl[first + rank] = (unsigned short)(c | (g << 8) | (key << 11));   // (TH / 4 <= 8 row groups, keys < 32)
 			}
 			TPROF(4);
 			__syncthreads();
@@ -514,7 +527,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 				asm volatile("" : "+v"(tw));
 				cb_u2 ent2 = *(const cb_u2 *)(TABl + 4 * (tw <= NI / 4 ? tw : 0));
 				if (tw == NI / 4) ent2 = cb_u2{(cb_u32)nz, (cb_u32)nfast};
-				if (tw == NI / 4 + 1) ent2 = cb_u2{(cb_u32)ngen, 0u};
+				if (tw == NI / 4 + 1) ent2 = cb_u2{(cb_u32)ngen, (cb_u32)ntall};
 				__builtin_amdgcn_raw_buffer_store_b64(ent2, rplan, tw <= NI / 4 + 1 ? (cb_u32)(sidx * ENT + tw * 8) : OOB, 0, 0);
 			}
 		} else {
@@ -522,20 +535,68 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			nz = min(__builtin_amdgcn_readfirstlane((int)hdr[0]), NI);   // (clamped: an entry nobody wrote must not turn into a long loop)
 			nfast = __builtin_amdgcn_readfirstlane((int)hdr[1]);
 			ngen = __builtin_amdgcn_readfirstlane((int)hdr[2]);
+			ntall = min(__builtin_amdgcn_readfirstlane((int)hdr[3]), nz);
 		}
-		const int nchunks = (nz + 63) >> 6;
+		// A step's tallest chunk is one wave walking a chain of thousands of instructions while the block's other waves wait at
+		// the barrier.  Where a step has only a few tall items (flat regions entering the tile) they are taken apart instead: a
+		// unit of 16 items, one OUTPUT per lane -- the same rows in the same order, one accumulator each, 0.6 of the chain, on four
+		// times the waves.  (Where most of the step is tall the chunks balance by themselves and the shared walk is the cheaper one.)
+		const int nsplit = (A > 4 && ntall <= NSPLIT_MAX) ? ntall : 0;
+		const int usplit = (nsplit + 15) >> 4;
+		const int nunits = usplit + ((nz - nsplit + 63) >> 6);
 
-		// ---- chunks of 64 items, tallest first ----------------------------------------------------------------------
+		// ---- work units, tallest first: split units of 16 items, then chunks of 64 items -----------------------------------
 		for (;;) {
-			int chunk = 0;
-			if (lane == 0) chunk = (int)atomicAdd(&CTRl[0], 1u);
-			chunk = __builtin_amdgcn_readfirstlane(chunk);
-			if (chunk >= nchunks) break;
-			const int idx = chunk * 64 + lane;
+			int unit = 0;
+			if (lane == 0) unit = (int)atomicAdd(&CTRl[0], 1u);
+			unit = __builtin_amdgcn_readfirstlane(unit);
+			if (unit >= nunits) break;
+			if (unit < usplit) {
+				const int it = unit * 16 + (lane >> 2), j = lane & 3;
+				const bool hasi = it < nsplit;
+				const cb_u32 ent = TABl[hasi ? it : 0];
+				const int c = (int)(ent & 0xffu), g = (int)((ent >> 8) & 7u);
+				const int E = __builtin_amdgcn_readfirstlane((int)(ent >> 11)) - 1;   // lane 0: the unit's tallest item, key = height + 1
+				// the item's rows (as every lane of the item walks them: one LDS address per item and row), this lane's output inside them
+				int s0[4], e0[4], top, bot;
+				item_rows(c, g, s0, e0, top, bot);
+				const int sj = j == 0 ? s0[0] : j == 1 ? s0[1] : j == 2 ? s0[2] : s0[3];
+				const int ej = j == 0 ? e0[0] : j == 1 ? e0[1] : j == 2 ? e0[2] : e0[3];
+				const bool outp = hasi && ej >= 0;
+				const int ext = hasi ? bot - top + 1 : 0;
+				// rows of the walk that belong to this output: bits sj - top .. ej - top
+				cb_u32 mine = outp ? ((2u << (ej - top)) - (1u << (sj - top))) : 0u;
+				asm volatile("" : "+v"(mine));
+				cb_u32 extbit = 1u << ext;
+				asm volatile("" : "+v"(extbit));
+				const cb_u32 Ebit = 1u << E;
+				int slot = hasi ? base + top : 0;
+				slot = slot >= RR ? slot - RR : slot;
+				const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;
+				float sum = 0.0f;
+				int Pn = 0;
+				__builtin_amdgcn_s_setprio(2);
+				cb_u32 mnext = ext > 0 ? (cb_u32)Ml[slot * TW + c] : 0u;
+				for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 1) {
+					const cb_u32 m = mnext;
+					const int n = (mine & ibit) ? (int)(m >> 8) : 0;
+					const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
+					slot = slot + 1 == RR ? 0 : slot + 1;
+					const cb_u32 mr = Ml[slot * TW + c];
+					mnext = (ibit << 1) < extbit ? mr : 0u;
+					tile_taps1<(A > 4)>(pa, n, sum);
+					Pn += n;
+				}
+				__builtin_amdgcn_s_setprio(0);
+				if (outp) OUTl[(4 * g + j) * TW + c] = sum / (float)Pn;
+				continue;
+			}
+			const int i0 = nsplit + (unit - usplit) * 64;   // first item of the chunk
+			const int idx = i0 + lane;
 			const bool has = idx < nz;
 			const cb_u32 ent = TABl[has ? idx : 0];
-			const int c = (int)(ent & 0xffu), g = (int)(ent >> 8);
-			if (chunk * 64 >= nfast) {
+			const int c = (int)(ent & 0xffu), g = (int)((ent >> 8) & 7u);
+			if (i0 >= nfast) {
 				// every item of the chunk is four 3 x 3 supports: six rows x three values, nine additions per output in the
 				// reference's order, no lengths to look at
 				int slot = base + A + 4 * g - 1;
@@ -555,7 +616,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 					if (has) OUTl[(4 * g + j) * TW + c] = fs[j] / 9.0f;
 				continue;
 			}
-			if (chunk * 64 >= ngen) {
+			if (i0 >= ngen) {
 				// every item of the chunk has four outputs of three rows each (the minimal class's items at its end included): window
 				// row r of the item's six is row r - j of output j, so it feeds outputs max(0, r - 2) .. min(3, r) -- no first / last
 				// rows to watch, only the runs to look up
@@ -611,7 +672,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			const int ext = has ? bot - top + 1 : 0;
 			// lane 0 holds the chunk's tallest item -- except that heights 1 and 2 share a key and that the six-row classes are sorted
 			// behind every other class
-			const int E = max(max(__builtin_amdgcn_readfirstlane(ext), 2), chunk * 64 + 64 > ngen ? 6 : 0);
+			const int E = max(max(__builtin_amdgcn_readfirstlane(ext), 2), i0 + 64 > ngen ? 6 : 0);
 #ifndef MC_TILE_NO_SETPRIO
 			if (E >= 14) __builtin_amdgcn_s_setprio(2);   // a tall chunk is the step's critical path (one wave, a chain of thousands of instructions)
 #endif
@@ -802,7 +863,7 @@ size_t cbca_plan_bytes(int D, int H, int W) { return plan_layout(D, H, W).total;
 template <int A, int TW, int TH, int NWAVES, int MODE>
 static int cbca_tiles_launch_mode(CbcaArgs P, bool nt, hipStream_t st)
 {
-	using G = TileGeo<A, TW, TH>;
+	using G = TileGeo<A, TW, TH, MODE>;
 	const int64_t blocks = (int64_t)cdiv((int64_t)P.gx * P.gy, 8) * 8 * P.nd;
 	if (blocks > 0x7fffffff) {
 		set_error("cbca_tiles: %lld blocks", (long long)blocks);
