@@ -35,7 +35,7 @@ namespace mc {
 
 #ifdef MC_TILE_PROF
 __device__ unsigned long long tile_prof[4096];
-#define TPROF(slot) do { if (prof_on && lane == 0) tile_prof[(step_no * 4 + wv_) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TPROF(slot) do { if (prof_on && lane == 0) tile_prof[(step_no * 8 + wv_) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TPROF(slot) do { } while (0)
 #endif
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	for (int y0 = ys, rrn = RR; y0 < ye; y0 += TH, rrn += TH, ++sidx) {
 		const bool more = y0 + TH < ye;
 #ifdef MC_TILE_PROF
-		const bool prof_on = blockIdx.x == gridDim.x / 2 + 8 && step_no < 12;
+		const bool prof_on = blockIdx.x == MC_TILE_PROF && step_no < 16;   // (-DMC_TILE_PROF=<block to look at>)
 #endif
 		TPROF(0);
 		TPROF(1);
