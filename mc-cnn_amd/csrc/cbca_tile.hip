@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 		MODE ? (void *)((char *)P.plan + ((size_t)d * (size_t)(P.gx * P.gy) + (size_t)region) * (size_t)P.spr * ENT) : nullptr, 0, MODE ? P.spr * ENT : 0, 0x00020000);
 
 	// ... and behind the tables, per plane, the combined runs (2 bytes per pixel) and vertical arms (1 byte) exactly as the
-	// first pass committed them to its ring: rows of Wp = W rounded up to 4 pixels
+	// first pass committed them to its ring: rows of Wp = W rounded up to whole tiles
 	const int Wp = P.wp;
 	const __amdgpu_buffer_rsrc_t rpm = __builtin_amdgcn_make_buffer_rsrc(MODE ? (void *)((char *)P.plan + P.plan_m + (size_t)d * H * Wp * 2) : nullptr, 0,
 	                                                                     MODE ? H * Wp * 2 : 0, 0x00020000);
@@ -845,14 +845,14 @@ static void tile_regions(int H, int W, int TW, int TH, int &gx, int &gy, int &rb
 
 // the product's geometries (128 x 16 tiles for either arm class) share one plan layout
 constexpr int PLAN_TW = 128, PLAN_TH = 16;
-// [item tables: D x regions x steps per region entries | combined runs (D, H, Wp) u16 | vertical arms (D, H, Wp) u8]
+// [item tables: D x regions x steps per region entries | combined runs (D, H, Wp) u16 | vertical arms (D, H, Wp) u8], Wp = W rounded up to whole tiles
 struct PlanLayout { size_t m, ud, total; int wp; };
 static PlanLayout plan_layout(int D, int H, int W)
 {
 	int gx, gy, rb;
 	tile_regions(H, W, PLAN_TW, PLAN_TH, gx, gy, rb);
 	PlanLayout L;
-	L.wp = (W + 3) / 4 * 4;
+	L.wp = gx * PLAN_TW;   // rows of whole tiles: a tile's 128 pixels of a row are two / one aligned 128-byte lines
 	L.m = ((size_t)D * gx * gy * (rb / PLAN_TH) * TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES + 255) / 256 * 256;
 	L.ud = L.m + ((size_t)D * H * L.wp * 2 + 255) / 256 * 256;
 	L.total = L.ud + (size_t)D * H * L.wp;

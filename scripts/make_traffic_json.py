@@ -33,7 +33,16 @@ def main(d, config):
             wr = sum(acc[k]["WRITE_SIZE"]) / max(1, len(acc[k]["WRITE_SIZE"])) * 1024
             per_kernel[k[:90]] = dict(read=round(rd), write=round(wr))
             tot += rd + wr
-        out[g] = round(tot if g == "cbca" else tot / len(ks))
+        if g == "cbca":
+            # bytes of ALL dispatches of the group / iterations; an iteration launches one kernel of each family (strip, tile<4, tile<13:
+            # the plan-writing and plan-reading instances of a tile family are different kernels of the same family)
+            fam = lambda k: "strip" if "cbca_strip" in k else ("tile4" if "cbca_tile_kernel<4," in k else "tile13")
+            allb = sum((2 * sum(acc[k]["FETCH_SIZE"]) + sum(acc[k]["WRITE_SIZE"])) * 1024 for k in ks)
+            iters = max(sum(len(acc[k]["FETCH_SIZE"]) for k in ks if fam(k) == f) for f in ("strip", "tile4", "tile13"))
+            out[g] = round(allb / max(1, iters))
+            out["cbca_iterations_seen"] = iters
+        else:
+            out[g] = round(tot / len(ks))
         out[g + "_kernels"] = per_kernel
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_%s.json" % config)
     json.dump(out, open(path, "w"), indent=1)
