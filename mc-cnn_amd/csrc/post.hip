@@ -41,6 +41,40 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
 	}
 }
 
+// ... 16 bytes per lane on both sides where every extent and leading dimension is a multiple of 4 and the bases are aligned
+// (the volumes of the pipeline: H*W and ds are; D mostly is): a quarter of the memory instructions
+typedef float post_f4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ void __launch_bounds__(256) transpose4_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t R,
+                                                         int64_t Cn, int64_t ldin, int64_t ldout, float s)
+{
+	__shared__ float tile[64][65];
+	const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+	const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const int row = ly + 16 * k;
+		const int64_t r = r0 + row, c = c0 + 4 * lx;
+		if (r < R && c < Cn) {
+			const post_f4 *p = (const post_f4 *)(in + r * ldin + c);
+			const post_f4 v = NT ? __builtin_nontemporal_load(p) : *p;
+			tile[row][4 * lx + 0] = v.x; tile[row][4 * lx + 1] = v.y; tile[row][4 * lx + 2] = v.z; tile[row][4 * lx + 3] = v.w;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const int col = ly + 16 * k;
+		const int64_t c = c0 + col, r = r0 + 4 * lx;
+		if (c < Cn && r < R) {
+			const post_f4 v = {tile[4 * lx + 0][col] * s, tile[4 * lx + 1][col] * s, tile[4 * lx + 2][col] * s, tile[4 * lx + 3][col] * s};
+			post_f4 *q = (post_f4 *)(out + c * ldout + r);
+			if (NT) __builtin_nontemporal_store(v, q);
+			else *q = v;
+		}
+	}
+}
+
 int fill_nan(float *p, int64_t n, hipStream_t st)
 {
 	if (n <= 0) return 0;
@@ -61,6 +95,11 @@ int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, 
 {
 	// the long axis goes to grid.x (grid.y is limited to 65535 blocks)
 	const bool use_nt = nt >= 0 ? nt != 0 : R * Cn * 4 > ((int64_t)768 << 20);
+	if (R % 4 == 0 && Cn % 4 == 0 && ldin % 4 == 0 && ldout % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0) {
+		if (use_nt) hipLaunchKernelGGL(transpose4_kernel<true>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+		else hipLaunchKernelGGL(transpose4_kernel<false>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+		return check_launch("transpose");
+	}
 	if (use_nt) hipLaunchKernelGGL(transpose_kernel<true>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
 	else hipLaunchKernelGGL(transpose_kernel<false>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
 	return check_launch("transpose");
@@ -107,6 +146,24 @@ __global__ void __launch_bounds__(256) argmin_dhw_kernel(const float *__restrict
 	out[p] = (float)(argmin + base1);
 }
 
+// ... four pixels per thread (16-byte loads) where the plane stride and the bases allow
+__global__ void __launch_bounds__(256) argmin_dhw4_kernel(const float *__restrict__ vol, float *__restrict__ out, int D, int64_t HW,
+                                                          int base1)
+{
+	const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	if (p >= HW) return;
+	int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+	float m0 = __builtin_inff(), m1 = m0, m2 = m0, m3 = m0;
+	for (int i = 0; i < D; ++i) {
+		const post_f4 v = __builtin_nontemporal_load((const post_f4 *)(vol + i * HW + p));
+		if (v.x < m0) { m0 = v.x; a0 = i; }
+		if (v.y < m1) { m1 = v.y; a1 = i; }
+		if (v.z < m2) { m2 = v.z; a2 = i; }
+		if (v.w < m3) { m3 = v.w; a3 = i; }
+	}
+	*(post_f4 *)(out + p) = post_f4{(float)(a0 + base1), (float)(a1 + base1), (float)(a2 + base1), (float)(a3 + base1)};
+}
+
 // (H,W,ds) layout: one wave per pixel, lanes over d.
 __global__ void __launch_bounds__(256) argmin_hwd_kernel(const float *__restrict__ vol, float *__restrict__ out, int D, int ds,
                                                          int64_t HW)
@@ -134,7 +191,10 @@ __global__ void __launch_bounds__(256) argmin_hwd_kernel(const float *__restrict
 int argmin_dhw(const float *vol, float *out, int D, int H, int W, int base1, hipStream_t st)
 {
 	const int64_t HW = (int64_t)H * W;
-	hipLaunchKernelGGL(argmin_dhw_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, vol, out, D, HW, base1);
+	if (HW % 4 == 0 && (uintptr_t)vol % 16 == 0 && (uintptr_t)out % 16 == 0)
+		hipLaunchKernelGGL(argmin_dhw4_kernel, dim3(cdiv(HW / 4, 256)), dim3(256), 0, st, vol, out, D, HW, base1);
+	else
+		hipLaunchKernelGGL(argmin_dhw_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, vol, out, D, HW, base1);
 	return check_launch("argmin_dhw");
 }
 

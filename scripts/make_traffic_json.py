@@ -22,7 +22,7 @@ def main(d, config):
     # cbca: one ITERATION over one volume = the launches of cbca_by_arms (tile instances + strip kernel, all but one of which
     # stand down at their first instruction): summed, not averaged
     groups = {"sgm": ("sgm_pass_kernel",), "cbca": ("cbca_strip_kernel", "cbca_tile_kernel"), "join": ("join_owner_kernel",),
-              "transpose": ("transpose_kernel",)}
+              "transpose": ("transpose_kernel", "transpose4_kernel")}
     for g, pat in groups.items():
         ks = [k for k in acc if any(q in k for q in pat)]
         if not ks:

@@ -50,7 +50,7 @@ def test_cbca_plane_range(mc, oracle):
 
 
 @pytest.mark.parametrize("nt", [0, 1])
-@pytest.mark.parametrize("R,Cn", [(228, 370 * 7), (65, 129), (256, 1000)])
+@pytest.mark.parametrize("R,Cn", [(228, 370 * 7), (65, 129), (256, 1000), (228, 2592), (4, 8), (68, 132), (228, 453620 // 19)])   # (16-byte and 4-byte paths)
 def test_transposes_forced_cache_policy(mc, R, Cn, nt):
     rng = np.random.default_rng(R)
     a = rng.standard_normal((R, Cn)).astype(np.float32)

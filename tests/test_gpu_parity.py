@@ -171,7 +171,7 @@ def test_sgm2_accumulates(mc, oracle):
     assert_same(host(out), want, "sgm2 accumulate")
 
 
-@pytest.mark.parametrize("H,W,D", SHAPES[:5])
+@pytest.mark.parametrize("H,W,D", SHAPES[:5] + [(12, 64, 8), (30, 130, 20), (16, 100, 68)])   # (the last three: H*W and D multiples of 4, the 16-byte kernels)
 def test_transposes_argmin(mc, oracle, H, W, D):
     vl, _ = raw_volumes(D, H, W, seed=31)
     vl[:, 0, 0] = np.nan  # all-NaN pixel -> index 0
