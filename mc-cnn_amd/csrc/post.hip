@@ -44,34 +44,42 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
 // ... 16 bytes per lane on both sides where every extent and leading dimension is a multiple of 4 and the bases are aligned
 // (the volumes of the pipeline: H*W and ds are; D mostly is): a quarter of the memory instructions
 typedef float post_f4 __attribute__((ext_vector_type(4)));
-template <bool NT>
+// A block walks ALL tiles along the short dimension (LOOP_R: the rows, else the columns) of its 64 columns / rows: the 64-float pieces it writes to
+// (or reads from) one pixel's run of disparities then follow each other within microseconds, so the L2 sees whole 128-byte lines instead of thirds
+// of them from blocks that run at different times (a 228-float run is 7.1 lines; measured at 370x1226x228: 1.25x the bytes written)
+template <bool NT, bool LOOP_R>
 __global__ void __launch_bounds__(256) transpose4_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t R,
                                                          int64_t Cn, int64_t ldin, int64_t ldout, float s)
 {
 	__shared__ float tile[64][65];
-	const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
 	const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+	const int64_t fixed0 = (int64_t)blockIdx.x * 64;
+	const int64_t nloop = LOOP_R ? R : Cn;
+	for (int64_t t0 = 0; t0 < nloop; t0 += 64) {
+		const int64_t c0 = LOOP_R ? fixed0 : t0, r0 = LOOP_R ? t0 : fixed0;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const int row = ly + 16 * k;
-		const int64_t r = r0 + row, c = c0 + 4 * lx;
-		if (r < R && c < Cn) {
-			const post_f4 *p = (const post_f4 *)(in + r * ldin + c);
-			const post_f4 v = NT ? __builtin_nontemporal_load(p) : *p;
-			tile[row][4 * lx + 0] = v.x; tile[row][4 * lx + 1] = v.y; tile[row][4 * lx + 2] = v.z; tile[row][4 * lx + 3] = v.w;
+		for (int k = 0; k < 4; ++k) {
+			const int row = ly + 16 * k;
+			const int64_t r = r0 + row, c = c0 + 4 * lx;
+			if (r < R && c < Cn) {
+				const post_f4 *p = (const post_f4 *)(in + r * ldin + c);
+				const post_f4 v = NT ? __builtin_nontemporal_load(p) : *p;
+				tile[row][4 * lx + 0] = v.x; tile[row][4 * lx + 1] = v.y; tile[row][4 * lx + 2] = v.z; tile[row][4 * lx + 3] = v.w;
+			}
 		}
-	}
-	__syncthreads();
+		__syncthreads();
 #pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const int col = ly + 16 * k;
-		const int64_t c = c0 + col, r = r0 + 4 * lx;
-		if (c < Cn && r < R) {
-			const post_f4 v = {tile[4 * lx + 0][col] * s, tile[4 * lx + 1][col] * s, tile[4 * lx + 2][col] * s, tile[4 * lx + 3][col] * s};
-			post_f4 *q = (post_f4 *)(out + c * ldout + r);
-			if (NT) __builtin_nontemporal_store(v, q);
-			else *q = v;
+		for (int k = 0; k < 4; ++k) {
+			const int col = ly + 16 * k;
+			const int64_t c = c0 + col, r = r0 + 4 * lx;
+			if (c < Cn && r < R) {
+				const post_f4 v = {tile[4 * lx + 0][col] * s, tile[4 * lx + 1][col] * s, tile[4 * lx + 2][col] * s, tile[4 * lx + 3][col] * s};
+				post_f4 *q = (post_f4 *)(out + c * ldout + r);
+				if (NT) __builtin_nontemporal_store(v, q);
+				else *q = v;
+			}
 		}
+		__syncthreads();
 	}
 }
 
@@ -96,8 +104,13 @@ int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, 
 	// the long axis goes to grid.x (grid.y is limited to 65535 blocks)
 	const bool use_nt = nt >= 0 ? nt != 0 : R * Cn * 4 > ((int64_t)768 << 20);
 	if (R % 4 == 0 && Cn % 4 == 0 && ldin % 4 == 0 && ldout % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0) {
-		if (use_nt) hipLaunchKernelGGL(transpose4_kernel<true>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
-		else hipLaunchKernelGGL(transpose4_kernel<false>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+		if (R <= Cn) {
+			if (use_nt) hipLaunchKernelGGL((transpose4_kernel<true, true>), dim3(cdiv(Cn, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+			else hipLaunchKernelGGL((transpose4_kernel<false, true>), dim3(cdiv(Cn, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+		} else {
+			if (use_nt) hipLaunchKernelGGL((transpose4_kernel<true, false>), dim3(cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+			else hipLaunchKernelGGL((transpose4_kernel<false, false>), dim3(cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
+		}
 		return check_launch("transpose");
 	}
 	if (use_nt) hipLaunchKernelGGL(transpose_kernel<true>, dim3(cdiv(Cn, 64), cdiv(R, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
