@@ -1,7 +1,9 @@
 """CPU model (tuning aid, no GPU): what the tile kernel's steps look like on a pair -- per 128 x 16 step the items' heights, the
 64-item chunks after the sort, an instruction estimate of every chunk (ISA counts of cbca_tile.hip) -- to see how much of a launch is
 bound by the step's tallest chunk (one wave walking a chain) and how much by total instruction issue.
-    python scripts/model/tile_steps.py [natural|sample] [d ...]"""
+    python scripts/model/tile_steps.py [natural|sample] [d ...] [--reg3] [--wb=N] [--uni=E] [--size=HxWxD]
+--reg3: with the class for items of four three-row outputs; --wb: secondary sort key (widest run // N); --uni: count rows of chunks of >= E rows on which
+every walking lane has the same run length."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +12,9 @@ from oracle import cpu_oracle as oracle
 from util import natural_pair, sample_pair
 
 H, W, D, L1, tau1 = 1000, 1500, 256, 14, 0.02
+for a in sys.argv:
+    if a.startswith("--size="):
+        H, W, D = (int(v) for v in a.split("=")[1].split("x"))
 A, TW, TH = 13, 128, 16
 which = sys.argv[1] if len(sys.argv) > 1 else "natural"
 REG3 = "--reg3" in sys.argv

@@ -54,6 +54,33 @@ def test_bad_arguments_fail_loudly_without_a_gpu(mc):
                           None) == EINVAL                              # neither features nor raw volumes
 
 
+def test_plan_and_workspace_sizes(mc):
+    """the plan the tile kernel keeps between the aggregation passes of a pair (cbca_tile.hip): item tables of 1 040 bytes per
+    (plane, region, step) and 3 bytes per voxel in rows of whole 128-pixel tiles; mc_predict's workspace holds two of them for
+    accurate parameter sets with L1 <= 14 and none where nothing would read them"""
+    lib = mc._lib.lib
+    assert lib.mc_cbca_plan_bytes(0, 8, 8) == 0
+    for D, H, W in ((256, 1000, 1500), (228, 370, 1226), (7, 33, 130)):
+        gx = -(-W // 128)
+        rows = 3 * D * H * gx * 128
+        got = lib.mc_cbca_plan_bytes(D, H, W)
+        steps = -(-H // 16)
+        assert rows + 1040 * D * gx * steps <= got <= rows + 1040 * D * gx * (steps + 8) + 1024, (D, H, W, got)
+    assert abs(lib.mc_cbca_plan_bytes(256, 1000, 1500) / (256 * 1000 * 1500) - 3.6) < 0.1   # bytes per voxel
+    fast, slow, mb = mc.make_params("kitti_fast"), mc.make_params("kitti_slow"), mc.make_params("mb_slow")
+    V = 4 * 228 * 370 * 1226
+    ws_fast = lib.mc_predict_workspace_bytes(C.byref(fast), 64, 228, 370, 1226)
+    ws_slow = lib.mc_predict_workspace_bytes(C.byref(slow), 0, 228, 370, 1226)
+    assert 6 * V < ws_fast < 6.3 * V
+    assert ws_slow - ws_fast >= 2 * lib.mc_cbca_plan_bytes(228, 370, 1226) - (1 << 20)          # two plans (and the packed arms)
+    assert ws_slow - ws_fast < 2 * lib.mc_cbca_plan_bytes(228, 370, 1226) + 64 * 370 * 1226
+    once = mc.make_params("kitti_slow"); once.cbca_i1, once.cbca_i2 = 1, 0     # a single pass per direction: nothing to keep
+    assert lib.mc_predict_workspace_bytes(C.byref(once), 0, 228, 370, 1226) < ws_fast + 64 * 370 * 1226
+    long_arms = mc.make_params("mb_slow"); long_arms.L1 = 20                     # strip kernel only: no plan
+    assert lib.mc_predict_workspace_bytes(C.byref(mb), 0, 256, 1000, 1500) - lib.mc_predict_workspace_bytes(C.byref(long_arms), 0, 256, 1000, 1500) >= \
+        2 * lib.mc_cbca_plan_bytes(256, 1000, 1500)
+
+
 def test_gaussian_host_matches_main_lua(mc):
     """gaussian(sigma), main.lua:528-540, runs on the host in doubles: checked here without a GPU."""
     import math

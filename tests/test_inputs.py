@@ -68,3 +68,13 @@ def test_sample_pair_fixture():
     assert abs(x0.mean()) < 1e-3 and abs(x0.std(ddof=1) - 1) < 1e-3
     t0, t1 = sample_pair(1000, 1500)
     assert t0.shape == (1000, 1500) and abs(t1.mean()) < 1e-3
+
+
+def test_tile_step_model_runs():
+    """scripts/model/tile_steps.py (the CPU model the tile kernel's leads were ranked with) at a toy size"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "model", "tile_steps.py"), "natural", "5", "--reg3", "--size=128x384x32"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mean critical path" in r.stdout and "work share" in r.stdout
