@@ -146,7 +146,7 @@ __device__ __forceinline__ void tile_taps3(unsigned pa, int n, float &a, float &
 typedef const float __attribute__((address_space(3))) *lds_cfp;
 __device__ __forceinline__ void tile_load9(float (&v)[9], unsigned pa)
 {
-	const lds_cfp p = (lds_cfp)pa;
+	const lds_cfp p = (lds_cfp)(__UINTPTR_TYPE__)pa;   // (LDS addresses are 32-bit)
 #pragma unroll
 	for (int t = 0; t < 9; ++t) v[t] = p[t];
 }
