@@ -187,13 +187,12 @@ __global__ void __launch_bounds__(256) join_mfma_kernel(const float *__restrict_
 // row's features (re-read by every wave of the row) out of it
 #define MC_JOIN_STORE_AUX 2
 
-template <int KSTEPS, int SIDE>
+template <int KSTEPS, int SIDE, int NT>
 __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, const float *__restrict__ fR, float *__restrict__ vol,
                                                  int C, int D, int ds, int H, int W, int y, int tile0, float *__restrict__ rings)
 {
 	// A wave owns TWO adjacent tiles (64 pixels) of one volume: both multiply against the same partner tile in the same
 	// step (with disparity offsets one tile apart), so every partner tile is fetched once per two tile products.
-	constexpr int NT = 2;
 	const int lane = threadIdx.x & 63;
 	const int nl = lane & 31, kh = lane >> 5;
 	const int64_t HW = (int64_t)H * W;
@@ -325,12 +324,15 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 	}
 }
 
-template <int KSTEPS>
+#ifndef MC_JOIN_NT
+#define MC_JOIN_NT 2
+#endif
+template <int KSTEPS, int NT = MC_JOIN_NT>
 __global__ void __launch_bounds__(256) join_owner_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
                                                          float *__restrict__ volL, float *__restrict__ volR, int C, int D, int ds,
                                                          int H, int W, int pairs_per_row)
 {
-	__shared__ __attribute__((aligned(16))) float rings[4][2 * 32 * 64];
+	__shared__ __attribute__((aligned(16))) float rings[4][NT * 32 * 64];
 	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	// XCD-aware mapping as in join_mfma_kernel: all blocks of one image row on one XCD
 	const int b = blockIdx.x;
@@ -339,8 +341,8 @@ __global__ void __launch_bounds__(256) join_owner_kernel(const float *__restrict
 	const int y = (k / blocks_per_row) * 8 + xcd;
 	const int w = (k % blocks_per_row) * 4 + wid;
 	if (y >= H || w >= 2 * pairs_per_row) return;
-	if (w < pairs_per_row) join_owner_tiles<KSTEPS, 0>(fL, fR, volL, C, D, ds, H, W, y, 2 * w, rings[wid]);
-	else join_owner_tiles<KSTEPS, 1>(fL, fR, volR, C, D, ds, H, W, y, 2 * (w - pairs_per_row), rings[wid]);
+	if (w < pairs_per_row) join_owner_tiles<KSTEPS, 0, NT>(fL, fR, volL, C, D, ds, H, W, y, NT * w, rings[wid]);
+	else join_owner_tiles<KSTEPS, 1, NT>(fL, fR, volR, C, D, ds, H, W, y, NT * (w - pairs_per_row), rings[wid]);
 }
 
 // fix_border (main.lua:922-927) on (H,W,ds): the n outermost pixels of one side replicate the
@@ -366,7 +368,7 @@ int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, 
 	const int ks = (C + 1) / 2;
 	const dim3 block(256);
 	if (ds % 4 == 0 && (uintptr_t)volL % 16 == 0 && (uintptr_t)volR % 16 == 0 && ks <= 32) {
-		const int tiles_own = ((W + 31) / 32 + 1) / 2;   // pairs of 32-pixel tiles per image row and volume
+		const int tiles_own = ((W + 31) / 32 + MC_JOIN_NT - 1) / MC_JOIN_NT;   // groups of MC_JOIN_NT 32-pixel tiles per image row and volume
 		const dim3 grid_o((unsigned)(rows8 * ((2 * tiles_own + 3) / 4) * 8));
 		if (ks <= 8) hipLaunchKernelGGL((join_owner_kernel<8>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
 		else if (ks <= 16) hipLaunchKernelGGL((join_owner_kernel<16>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
