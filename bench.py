@@ -325,7 +325,7 @@ def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None, xb=
     return rec
 
 
-def north_star_record(device, steps=5):
+def north_star_record(device, steps=5, with_cpu=True):
     """BASELINE.json north_star: the SGM + cross-aggregation sweep at 1500x1000x256 (mb-slow parameters,
     main.lua:132-144: 2 + 16 CBCA iterations), per volume, against SURVEY 8(d)'s 47 V = 72.2 GB budget."""
     import torch
@@ -334,7 +334,7 @@ def north_star_record(device, steps=5):
     cfg = CONFIGS["mb_slow"]
     preset, H, W, D, C, name = cfg
     prm = dict(mc.PRESETS[preset])
-    xb, kw, _ = make_inputs(cfg, 0, device)
+    xb, kw, host = make_inputs(cfg, 0, device)
     ws = Workspace(prm, D, H, W, device)
     out = torch.empty((1, 1, H, W), dtype=torch.float32, device=device)
 
@@ -371,6 +371,8 @@ def north_star_record(device, steps=5):
     rec["per_volume"]["box_copy_GBs"] = round(cr, 1)
     rec["per_volume"]["sweep_over_box_copy"] = round(budget / (sweep_ms * 1e-3) / 1e9 / cr, 4)
     rec["pair"] = PAIR_NOTE["texture"]
+    if with_cpu:   # the oracle on an 8-row band of this very workload (full width, full disp_max, 2 + 16 iterations): ~10 s of host time
+        rec["cpu_baseline"] = cpu_baseline(cfg, host, 8, runs=2)
     rec["realistic_pair"] = north_star_realistic(device, "natural")
     rec["realistic_pair_sample"] = north_star_realistic(device, "sample")
     return rec
@@ -650,7 +652,7 @@ def main():
 
     north = None
     if rank == 0 and world == 1 and args.config == "kitti_fast" and not args.no_north_star:
-        north = north_star_record(device)
+        north = north_star_record(device, with_cpu=not args.no_cpu_baseline)
 
     if rank == 0:
         line = {
