@@ -55,12 +55,12 @@ struct TileGeo {
 	static constexpr int RR = TH + 2 * A;             // ring rows: the window of one step
 	static constexpr int NI = TW * (TH / 4);          // items of a step: column x 4 rows
 	static constexpr int NG = NI / 64;                // groups of 64 consecutive items (one wave's worth)
-	static constexpr int NKEY = 32;                   // sort keys: 0 nothing to compute, 1 four 3 x 3 supports, height + 1 otherwise (<= 2A + 5)
+	static constexpr int NKEY = 32;                   // sort keys: 0 nothing to compute, 1 four 3 x 3 supports, 2 four three-row outputs, height + 1 otherwise (<= 2A + 5)
 	static constexpr int V_BYTES = RR * SW * 4;
 	static constexpr int M_BYTES = (RR * TW * 2 + 15) & ~15;   // runs: output columns only (a run is looked up in the item's own column)
 	static constexpr int UD_BYTES = (RR * TW + 15) & ~15;      // up | down << 4 per pixel, 0xff = no output here
 	static constexpr int OUT_BYTES = TH * TW * 4;
-	static constexpr int TAB_BYTES = NI * 2 + 16;          // sorted items, then (nz, nfast) of the step: one plan entry
+	static constexpr int TAB_BYTES = NI * 2 + 16;          // sorted items (column | row group << 8 | key << 11), then the step's class counts (nz, nfast, ngen, ntall): one plan entry
 	static constexpr int ENT_BYTES = TAB_BYTES;            // plan entry of one (plane, region, step)
 	static constexpr int MISC_BYTES = (MODE == 2 ? 0 : NG * NKEY * 4) + 16;   // items per group and key (sort); chunk counter
 	static constexpr int LDS_BYTES = V_BYTES + M_BYTES + UD_BYTES + OUT_BYTES + TAB_BYTES + MISC_BYTES;
