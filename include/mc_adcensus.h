@@ -223,7 +223,8 @@ enum { MC_SKIP_NONE = 0, MC_SKIP_CBCA = 1, MC_SKIP_SGM = 2, MC_SKIP_OCCLUSION = 
        MC_SKIP_MEDIAN = 5, MC_SKIP_BILATERAL = 6 };
 
 /* Workspace bytes mc_predict needs for the given problem: six volumes, six maps, the SGM edge classes, arms and packed
- * arm lengths; with cross-based aggregation and L1 > 5 also two lists of supports (17 bytes per voxel each). */
+ * arm lengths; for parameter sets that aggregate at least twice with L1 <= 14 also the tile kernel's plan (mc_cbca_plan_bytes,
+ * ~3.6 bytes per voxel) per computed direction. */
 size_t mc_predict_workspace_bytes(const mc_params *p, int C, int D, int H, int W);
 
 /* stereo_predict(x_batch, id), main.lua:929-1082, from the cost-volume stage on.

@@ -136,9 +136,27 @@ static int cbca_by_arms(const void *packed, const float *vin, float *vout, int D
 struct Plan {
 	int Dp;                 // padded pixel stride of the (H,W,Dp) volumes
 	size_t maps, arms, pack, vol, img, gk;
-	size_t cplan;           // per direction: the tile kernel's item order (cbca_tile.hip), 0 where it would not be reused
+	size_t cplan;           // per direction: the tile kernel's plan (cbca_tile.hip), 0 where it would not be reused
+	int nplan;              // directions that get one
 	size_t total;
 };
+
+// -sm_terminate / -sm_skip (main.lua:956,988-1040) are identical for both directions, so for the three volume stages they
+// reduce to effective iteration counts
+struct StageCounts { int cbca1, sgm, cbca2; bool active_after; };
+static StageCounts stage_counts(const mc_params *p)
+{
+	StageCounts c;
+	bool sm_active = p->sm_terminate != MC_SM_CNN;
+	c.cbca1 = (sm_active && p->sm_skip != MC_SKIP_CBCA) ? p->cbca_i1 : 0;
+	sm_active = sm_active && p->sm_terminate != MC_SM_CBCA1;
+	c.sgm = (sm_active && p->sm_skip != MC_SKIP_SGM) ? p->sgm_i : 0;
+	sm_active = sm_active && p->sm_terminate != MC_SM_SGM;
+	c.cbca2 = (sm_active && p->sm_skip != MC_SKIP_CBCA) ? p->cbca_i2 : 0;
+	sm_active = sm_active && p->sm_terminate != MC_SM_CBCA2;
+	c.active_after = sm_active;
+	return c;
+}
 
 static Plan make_plan(const mc_params *p, int D, int H, int W)
 {
@@ -153,9 +171,14 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	const int kr = (int)ceil(p->blur_sigma * 3);
 	const int ks = 2 * kr + 1;
 	pl.gk = align_up((size_t)ks * ks * sizeof(float), 256);
-	// the order of a step's items is the same in every aggregation pass over the pair: kept from the first pass on (~0.5 bytes per voxel)
-	pl.cplan = (p->cbca_i1 + p->cbca_i2 >= 2 && p->L1 - 1 <= 13) ? align_up(cbca_plan_bytes(D, H, W), 256) : 0;
-	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk + 2 * pl.cplan;
+	// the tile kernel's bookkeeping is the same in every aggregation pass over the pair and direction: kept from the first pass
+	// on (cbca_plan_bytes: ~3.6 bytes per voxel) -- where a second pass exists to read it (after -sm_skip / -sm_terminate),
+	// and per direction that is computed (left_only without the LR check: the left volume only; a caller who then asks for
+	// right-side outputs gets that direction without a plan)
+	const StageCounts sc = stage_counts(p);
+	pl.cplan = (sc.cbca1 + sc.cbca2 >= 2 && p->L1 - 1 <= 13) ? align_up(cbca_plan_bytes(D, H, W), 256) : 0;
+	pl.nplan = (p->left_only && !p->lr_check) ? 1 : 2;
+	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk + pl.nplan * pl.cplan;
 	return pl;
 }
 
@@ -228,7 +251,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	float *img[6];
 	for (int i = 0; i < 6; ++i) { img[i] = (float *)w; w += pl.img; }
 	float *gk = (float *)w; w += pl.gk;
-	void *cplan[2] = {pl.cplan ? (void *)w : nullptr, pl.cplan ? (void *)(w + pl.cplan) : nullptr};
+	void *cplan[2] = {pl.cplan ? (void *)w : nullptr, (pl.cplan && pl.nplan > 1) ? (void *)(w + pl.cplan) : nullptr};
 	int cplan_passes[2] = {0, 0};   // aggregation passes so far: the first one writes the plan, the others read it
 	const int Dp = pl.Dp;
 	int rc;
@@ -236,16 +259,9 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 
 	// index 0 = left volume (direction -1), 1 = right volume (direction +1)  (main.lua:986)
 	const int direction[2] = {-1, 1};
-	// sm_active / -sm_terminate / -sm_skip (main.lua:956,988-1040): identical for both directions, so they reduce to
-	// effective iteration counts of the three volume stages
-	bool sm_active = true;
-	sm_active = sm_active && p->sm_terminate != MC_SM_CNN;
-	const int n_cbca1 = (sm_active && p->sm_skip != MC_SKIP_CBCA) ? p->cbca_i1 : 0;
-	sm_active = sm_active && p->sm_terminate != MC_SM_CBCA1;
-	const int n_sgm = (sm_active && p->sm_skip != MC_SKIP_SGM) ? p->sgm_i : 0;
-	sm_active = sm_active && p->sm_terminate != MC_SM_SGM;
-	const int n_cbca2 = (sm_active && p->sm_skip != MC_SKIP_CBCA) ? p->cbca_i2 : 0;
-	sm_active = sm_active && p->sm_terminate != MC_SM_CBCA2;
+	const StageCounts sc = stage_counts(p);   // -sm_terminate / -sm_skip as effective iteration counts
+	const int n_cbca1 = sc.cbca1, n_sgm = sc.sgm, n_cbca2 = sc.cbca2;
+	bool sm_active = sc.active_after;
 	const bool use_cbca = (n_cbca1 + n_cbca2) > 0;
 	tm.mark(-1);
 

@@ -40,3 +40,18 @@ def mc():
     """The product package; importing it loads libmcadcensus.so or raises."""
     import mc_cnn_amd
     return mc_cnn_amd
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The reference's own kernels (oracle/_ref: /root/reference/adcensus.cu compiled for gfx950; test infrastructure).
+    Built only where /root/reference exists and shipped to the GPU box as a prebuilt .so.  Without it the parity story
+    would silently fall back to oracle-only, so: MC_REQUIRE_REF=1 (scripts/gpu_tests.sh, scripts/gpu_evidence.sh) turns
+    the skip into a failure."""
+    from oracle.ref_lib import RefLib, RefUnavailable
+    try:
+        return RefLib()
+    except RefUnavailable as e:
+        if os.environ.get("MC_REQUIRE_REF") == "1":
+            pytest.fail("MC_REQUIRE_REF=1 and the reference's kernels are not available: %s" % e)
+        pytest.skip(str(e))

@@ -24,15 +24,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-@pytest.fixture(scope="module")
-def ref():
-    from oracle.ref_lib import RefLib, RefUnavailable
-    try:
-        return RefLib()
-    except RefUnavailable as e:  # built only where /root/reference exists
-        pytest.skip(str(e))
-
-
 def assert_same_bits_dev(got, want, name):
     """bit-exact equality on the device, NaN == NaN, NaN masks identical"""
     got = got.reshape(-1)

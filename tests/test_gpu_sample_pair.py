@@ -22,7 +22,7 @@ torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from test_gpu_fullsize import assert_same_bits_dev, ref  # noqa: E402,F401  (fixture)
+from test_gpu_fullsize import assert_same_bits_dev  # noqa: E402  (the `ref` fixture lives in conftest.py)
 
 
 def test_baseline_config0_sample_pair_d70_fast(mc, oracle, ref):

@@ -13,15 +13,6 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-@pytest.fixture(scope="module")
-def ref():
-    from oracle.ref_lib import RefLib, RefUnavailable
-    try:
-        return RefLib()
-    except RefUnavailable as e:  # built only where /root/reference exists
-        pytest.skip(str(e))
-
-
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
 
