@@ -42,6 +42,10 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 size_t cbca_plan_bytes(int D, int H, int W);
 int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int route,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
+bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes);
+int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, hipStream_t st);
+int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
+              int route, hipStream_t st, const CbcaCfg &cfg);
 size_t conv3x3_workspace_bytes(int Cin, int Cout);
 int conv3x3(const float *in, const float *w, const float *bias, float *out, int N, int Cin, int Cout, int H, int W, int relu,
             void *workspace, hipStream_t st);
@@ -119,7 +123,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // known, < 0 where it is not: adcensus.cbca).  Arms <= 4: the tile kernel's short-arm instance.  Otherwise the pair's
 // route word (cbca_pack: arm classes actually present, share of pixels with unit arms) decides on the device between the
 // tile kernel's two instances and the strip kernel -- the launches that are not the pair's stand down at their first
-// instruction; nothing is read back by the host.
+// instruction; nothing is read back by the host.  cfg.lean (mc_predict, from the first pass of a direction on): pairs of the
+// strip kernel's route with arms <= 13 (textures) are served by the lean + list kernels out of the list cbca_classify wrote.
 static int cbca_by_arms(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int max_arm, hipStream_t st,
                         const CbcaCfg &cfg = CbcaCfg())
 {
@@ -129,6 +134,11 @@ static int cbca_by_arms(const void *packed, const float *vin, float *vout, int D
 	if (max_arm < 0 || max_arm <= 13) {
 		rc = cbca_tiles(packed, vin, vout, D, H, W, direction, 13, CR_TILE13, st, cfg);
 		if (rc) return rc;
+	}
+	if (cfg.lean) {   // textures (route CR_STRIP) out of the pair's list: the lean + list kernels, the strip kernel only if the list is unusable
+		rc = cbca_lean(packed, cfg.plan, cfg.plan_bytes, vin, vout, D, H, W, direction, CR_STRIP, st, cfg);
+		if (rc) return rc;
+		return cbca_strips(packed, vin, vout, D, H, W, direction, CR_STRIP_IF_NO_LIST, st, cfg);
 	}
 	return cbca_strips(packed, vin, vout, D, H, W, direction, max_arm > 13 ? CR_STRIP_OR_TILE13 : CR_STRIP, st, cfg);
 }
@@ -292,7 +302,16 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 				float *dst = other(v);
 				CbcaCfg cfg;
 				cfg.plan = cplan[v];
+				cfg.plan_bytes = pl.cplan;
+				const bool first = cplan_passes[v] == 0;
 				cfg.plan_mode = cplan[v] ? (cplan_passes[v]++ == 0 ? 1 : 2) : 0;
+				// the plan area serves whichever kernel the pair's route word picks: the tile kernel's plan (written by its first
+				// pass) or, on textures, the list of outputs whose support is not the minimal 3 x 3 (written here, before the first pass)
+				cfg.lean = packed_ok && cplan[v] && cbca_cap > 4 && cbca_cap <= 13 && cbca_lean_fits(D, H, W, pl.cplan);
+				if (cfg.lean && first) {
+					const int rc1 = cbca_classify(packed, cplan[v], pl.cplan, D, H, W, direction[v], CR_STRIP, st);
+					if (rc1) return rc1;
+				}
 				const int rc2 = packed_ok ? cbca_by_arms(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st, cfg)
 				                          : cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st);
 				if (rc2) return rc2;
@@ -608,13 +627,34 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
 	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws_cfg: image too large for 32-bit plane offsets");
-	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 7, "mc_cbca_ws_cfg: bad rb / nt / form");
-	MC_REQUIRE(d0 >= 0 && nd >= 0 && d0 + nd <= D, "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
+	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 9, "mc_cbca_ws_cfg: bad rb / nt / form");
+	MC_REQUIRE(d0 >= 0 && nd >= 0 && (form >= 8 || d0 + nd <= D), "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
 	CbcaCfg cfg;
 	cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd;
+	if (form >= 8) {   // lean + list kernels (textures): 8 lists the outputs whose support is not the minimal 3 x 3 behind the packed lengths first, 9 reads that list; rb = rows per wave, d0 = prefetch variant
+		const size_t off = align_up(cbca_scratch_bytes(H, W), 256), pb = cbca_plan_bytes(D, H, W);
+		MC_REQUIRE(scratch_bytes >= off + pb, "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu with the list", scratch_bytes, off + pb);
+		MC_REQUIRE((uintptr_t)scratch % 16 == 0, "mc_cbca_ws_cfg: scratch must be 16-byte aligned for the list");
+		MC_REQUIRE(cbca_lean_fits(D, H, W, pb), "mc_cbca_ws_cfg: volume too large for 32-bit list entries");
+		// (forms 8 / 9 take the whole volume; nd > 0 = entries the list may hold, to exercise the fallback)
+		cfg.plan = (char *)scratch + off;
+		cfg.plan_bytes = nd > 0 ? std::min(pb, (size_t)LH_WORDS * 4 + (size_t)nd * 4) : pb;
+		cfg.rb = rb;
+		cfg.variant = d0; cfg.d0 = 0; cfg.nd = 0;
+		if (form == 8) {
+			rc = cbca_classify(scratch, cfg.plan, cfg.plan_bytes, D, H, W, direction, CR_NOT_DIRECT, st);
+			if (rc) return rc;
+		}
+		rc = cbca_lean(scratch, cfg.plan, cfg.plan_bytes, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT, st, cfg);
+		if (rc) return rc;
+		cfg.rb = 0; cfg.variant = 0;
+		rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT_IF_NO_LIST, st, cfg);
+		if (rc) return rc;
+		return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);
+	}
 	if (form >= 4) {   // tile kernel with the item order kept behind the packed lengths: 4 / 5 write it (short- / long-arm instance), 6 / 7 read it
 		const size_t off = align_up(cbca_scratch_bytes(H, W), 256);
 		MC_REQUIRE(scratch_bytes >= off + cbca_plan_bytes(D, H, W), "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu with the plan", scratch_bytes,

@@ -180,7 +180,10 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 	__shared__ cb_u32 Mring[4][CS_RING * CS_COLS];
 	__shared__ float Rrow[4][CS_COLS];          // results of the current row (patched by the compacted pass)
 	__shared__ cb_u32 Clist[4][CS_COLS];        // outputs that need the general loop: frame column | up << 16 | down << 24
-	if (!cbca_gate(A.flags, A.route)) return;   // (the pair's arms call for another kernel)
+	if (A.route == CR_STRIP_IF_NO_LIST || A.route == CR_NOT_DIRECT_IF_NO_LIST) {   // fallback of the lean + list kernels: the pair's list did not fit (or was never written)
+		if (!cbca_gate(A.flags, A.route == CR_STRIP_IF_NO_LIST ? (int)CR_STRIP : (int)CR_NOT_DIRECT) ||
+		    list_valid((const uint32_t *)A.plan, A.D, A.H, A.W, A.direction)) return;
+	} else if (!cbca_gate(A.flags, A.route)) return;   // (the pair's arms call for another kernel)
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane descriptors stay in SGPRs
 	float *__restrict__ V = Vring[wv];
@@ -450,6 +453,7 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	A.d0 = d0; A.nd = nd;
 	A.flags = route >= 0 ? cs.flag : nullptr;
 	A.route = route;
+	A.plan = cfg.plan;   // (CR_STRIP_IF_NO_LIST: the list header the launch looks at)
 	A.gx = (int)cdiv(W, CS_STEP);
 	// output rows per strip: 40 (5 % of halo rows) unless that leaves fewer than ~16 K waves -- at KITTI size (5 strips x
 	// 228 planes) 27 and 20 rows measured 5 % faster than 40, 53 rows 18 % slower

@@ -55,7 +55,19 @@ enum { CR_TILE4 = 0,          // every arm <= 4 (L1 <= 5): tile kernel, short-ar
        // launch conditions that are not a single route (CbcaArgs::route):
        CR_ARMS_LE4 = 16, CR_ARMS_LE13 = 17,   // the forced tile instances of the test hook: any pair whose arms fit
        CR_NOT_DIRECT = 18,                    // the forced strip kernel: any pair the packed form holds
-       CR_STRIP_OR_TILE13 = 19 };             // strip kernel where L1 > 14 is known: the routes of longer arms and of arms <= 13 alike
+       CR_STRIP_OR_TILE13 = 19,               // strip kernel where L1 > 14 is known: the routes of longer arms and of arms <= 13 alike
+       CR_STRIP_IF_NO_LIST = 20,              // strip kernel as the fallback of the lean + list kernels (cbca_lean.hip): route CR_STRIP and no usable list
+       CR_NOT_DIRECT_IF_NO_LIST = 21 };       // ... of the forced lean + list kernels of the test hook
+
+// head of the pair's plan area when the route is CR_STRIP (cbca_lean.hip): the list of outputs whose support is not the minimal 3 x 3
+enum { LH_COUNT = 0, LH_OVERFLOW = 1, LH_D = 2, LH_H = 3, LH_W = 4, LH_DIR = 5, LH_MAGIC = 6, LH_WORDS = 64 };   // (entries from word LH_WORDS on)
+constexpr uint32_t LH_MAGIC_VALUE = 0x4c495354u;
+// written by cbca_classify_kernel for exactly this problem, and complete
+__device__ __forceinline__ bool list_valid(const uint32_t *__restrict__ hdr, int D, int H, int W, int direction)
+{
+	return hdr[LH_MAGIC] == LH_MAGIC_VALUE && hdr[LH_D] == (uint32_t)D && hdr[LH_H] == (uint32_t)H && hdr[LH_W] == (uint32_t)W &&
+	       hdr[LH_DIR] == (uint32_t)(direction + 1) && !hdr[LH_OVERFLOW];
+}
 
 // does this launch run? (flags == nullptr: the caller knows the arms and launched exactly the right kernel)
 __device__ __forceinline__ bool cbca_gate(const uint32_t *__restrict__ flags, int route)
