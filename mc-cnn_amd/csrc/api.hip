@@ -43,7 +43,8 @@ size_t cbca_plan_bytes(int D, int H, int W);
 int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int route,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
 bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes);
-int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, hipStream_t st);
+int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, int rb, int cap_limit,
+                  hipStream_t st);
 int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
               int route, hipStream_t st, const CbcaCfg &cfg);
 size_t conv3x3_workspace_bytes(int Cin, int Cout);
@@ -309,7 +310,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 				// pass) or, on textures, the list of outputs whose support is not the minimal 3 x 3 (written here, before the first pass)
 				cfg.lean = packed_ok && cplan[v] && cbca_cap > 4 && cbca_cap <= 13 && cbca_lean_fits(D, H, W, pl.cplan);
 				if (cfg.lean && first) {
-					const int rc1 = cbca_classify(packed, cplan[v], pl.cplan, D, H, W, direction[v], CR_STRIP, st);
+					const int rc1 = cbca_classify(packed, cplan[v], pl.cplan, D, H, W, direction[v], CR_STRIP, 0, 0, st);
 					if (rc1) return rc1;
 				}
 				const int rc2 = packed_ok ? cbca_by_arms(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st, cfg)
@@ -639,18 +640,18 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 		MC_REQUIRE(scratch_bytes >= off + pb, "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu with the list", scratch_bytes, off + pb);
 		MC_REQUIRE((uintptr_t)scratch % 16 == 0, "mc_cbca_ws_cfg: scratch must be 16-byte aligned for the list");
 		MC_REQUIRE(cbca_lean_fits(D, H, W, pb), "mc_cbca_ws_cfg: volume too large for 32-bit list entries");
-		// (forms 8 / 9 take the whole volume; nd > 0 = entries the list may hold, to exercise the fallback)
+		// (forms 8 / 9 take the whole volume; nd > 0 = slots the list may hold, to exercise the fallback; d0: bits 0-1 rows in flight, bit 2 the listed outputs in a launch of their own)
 		cfg.plan = (char *)scratch + off;
-		cfg.plan_bytes = nd > 0 ? std::min(pb, (size_t)LH_WORDS * 4 + (size_t)nd * 4) : pb;
+		cfg.plan_bytes = pb;
 		cfg.rb = rb;
-		cfg.variant = d0; cfg.d0 = 0; cfg.nd = 0;
+		cfg.variant = d0; cfg.d0 = 0; cfg.nd = nd;
 		if (form == 8) {
-			rc = cbca_classify(scratch, cfg.plan, cfg.plan_bytes, D, H, W, direction, CR_NOT_DIRECT, st);
+			rc = cbca_classify(scratch, cfg.plan, cfg.plan_bytes, D, H, W, direction, CR_NOT_DIRECT, rb, nd, st);
 			if (rc) return rc;
 		}
 		rc = cbca_lean(scratch, cfg.plan, cfg.plan_bytes, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT, st, cfg);
 		if (rc) return rc;
-		cfg.rb = 0; cfg.variant = 0;
+		cfg.lean_rb = rb; cfg.rb = 0; cfg.variant = 0; cfg.nd = 0;
 		rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT_IF_NO_LIST, st, cfg);
 		if (rc) return rc;
 		return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);

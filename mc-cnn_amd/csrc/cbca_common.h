@@ -35,6 +35,7 @@ struct CbcaArgs {
 	int spr;                      // ... steps per region
 	size_t plan_m, plan_ud;       // ... byte offsets of the combined runs / vertical arms behind the tables
 	int wp;                       // ... their row length in pixels
+	int lean_rb;                  // strip kernel as the lean kernels' fallback: rows per wave the pair's list must have been written for
 };
 
 
@@ -60,13 +61,13 @@ enum { CR_TILE4 = 0,          // every arm <= 4 (L1 <= 5): tile kernel, short-ar
        CR_NOT_DIRECT_IF_NO_LIST = 21 };       // ... of the forced lean + list kernels of the test hook
 
 // head of the pair's plan area when the route is CR_STRIP (cbca_lean.hip): the list of outputs whose support is not the minimal 3 x 3
-enum { LH_COUNT = 0, LH_OVERFLOW = 1, LH_D = 2, LH_H = 3, LH_W = 4, LH_DIR = 5, LH_MAGIC = 6, LH_WORDS = 64 };   // (entries from word LH_WORDS on)
+enum { LH_COUNT = 0, LH_OVERFLOW = 1, LH_D = 2, LH_H = 3, LH_W = 4, LH_DIR = 5, LH_MAGIC = 6, LH_RB = 7, LH_WORDS = 64 };   // (wave table from word LH_WORDS on, then the slots)
 constexpr uint32_t LH_MAGIC_VALUE = 0x4c495354u;
-// written by cbca_classify_kernel for exactly this problem, and complete
-__device__ __forceinline__ bool list_valid(const uint32_t *__restrict__ hdr, int D, int H, int W, int direction)
+// written by cbca_classify_kernel for exactly this problem and wave geometry (rb rows per wave), and complete
+__device__ __forceinline__ bool list_valid(const uint32_t *__restrict__ hdr, int D, int H, int W, int direction, int rb)
 {
 	return hdr[LH_MAGIC] == LH_MAGIC_VALUE && hdr[LH_D] == (uint32_t)D && hdr[LH_H] == (uint32_t)H && hdr[LH_W] == (uint32_t)W &&
-	       hdr[LH_DIR] == (uint32_t)(direction + 1) && !hdr[LH_OVERFLOW];
+	       hdr[LH_DIR] == (uint32_t)(direction + 1) && hdr[LH_RB] == (uint32_t)rb && !hdr[LH_OVERFLOW];
 }
 
 // does this launch run? (flags == nullptr: the caller knows the arms and launched exactly the right kernel)

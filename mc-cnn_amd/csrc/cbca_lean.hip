@@ -4,13 +4,13 @@
 // Whether an output's support is the minimal 3 x 3 depends on the pair's arms and the plane only, not on the volume, and
 // mc_predict aggregates a pair 2 + 16 times per direction (main.lua:998-1001, 1033-1039).  So the work is split once per
 // pair and direction:
-//   cbca_classify_kernel  (arms only)  LISTS every output with a partner whose support is NOT the minimal 3 x 3 (4 bytes
-//                                      per entry: the voxel index) in the pair's plan area;
+//   cbca_classify_kernel  (arms only)  LISTS every output with a partner whose support is NOT the minimal 3 x 3, with the
+//                                      support's shape (16 bytes per entry), per wave of the lean kernel, in the pair's plan area;
 //   cbca_lean_kernel      (per pass)   computes the minimal 3 x 3 mean for EVERY output -- nine additions in the reference's
 //                                      order and an IEEE divide, out of a three-row register window, neighbours' columns
-//                                      through DPP: no arm lengths, no LDS, no tests; the plane is read once and written once;
-//   cbca_list_kernel      (per pass)   re-runs the reference's loop for the listed outputs (one thread per entry, reads
-//                                      through L2) and overwrites them.
+//                                      through DPP: no arm lengths, no LDS, no tests; the plane is read once and written once --
+//                                      and then re-runs the reference's loop for the wave's listed outputs (one lane per
+//                                      entry, values through L1 / L2: the wave has just read those rows) and overwrites them.
 // Outputs without a partner are copied through by the lean kernel (adcensus.cu:353-354).  The strip kernel (cbca.hip), which
 // does all of this per pass, remains what adcensus.cbca runs on its own (no state between calls) and the fallback when the
 // list does not fit.
@@ -25,19 +25,23 @@ struct LeanArgs {
 	const uint32_t *p0, *p1;     // packed arm lengths (H,W)
 	const float *vin;
 	float *vout;
-	uint32_t *hdr;               // list header (LH_*), the entries follow it
-	uint32_t cap;                // entries the list can hold
+	uint32_t *hdr;               // list header (LH_*); behind it the wave table and the slots
+	uint32_t wtab_words;         // word offset of the wave table: per wave of the lean kernel {first segment's slot + 1, 0}
+	uint32_t slots_words;        // word offset of the slots (16 bytes each)
+	uint32_t cap;                // slots the list can hold
 	int D, H, W, direction;
 	int rb, gx, gy;              // rows per wave, strips per row, row chunks
 	const uint32_t *flags;       // cbca_pack's flag words
 	int route;
 };
 
+__device__ __forceinline__ bool lean_list_valid(const LeanArgs &A) { return list_valid(A.hdr, A.D, A.H, A.W, A.direction, A.rb); }
+
 // wave -> (plane, row chunk, strip of 256 columns); strips fastest, so that the waves of a block are neighbours in a row
 // (a strip's edge columns are its neighbours' lines: L1 / L2 hits)
-__device__ __forceinline__ bool lean_wave(const LeanArgs &A, int wv, int &d, int &y0, int &y1, int &x0)
+__device__ __forceinline__ bool lean_wave(const LeanArgs &A, int wv, long long &w, int &d, int &y0, int &y1, int &x0)
 {
-	const long long w = (long long)blockIdx.x * 4 + wv;
+	w = (long long)blockIdx.x * 4 + wv;
 	const int strip = (int)(w % A.gx);
 	const long long t = w / A.gx;
 	const int chunk = (int)(t % A.gy);
@@ -48,13 +52,81 @@ __device__ __forceinline__ bool lean_wave(const LeanArgs &A, int wv, int &d, int
 	return d < A.D;
 }
 
+// byte j (0 .. 11) of the entry's words 1 .. 3
+__device__ __forceinline__ cb_u32 entry_byte(const cb_u4 &e, int j)
+{
+	const cb_u32 wsel = j < 4 ? e.y : (j < 8 ? e.z : e.w);
+	return (wsel >> ((j & 3) * 8)) & 0xffu;
+}
+
+// The wave's listed outputs: the reference's loop (rows ascending, x ascending, one accumulator, adcensus.cu:356-373), one lane
+// per entry.  An entry holds the voxel index and, where the support has at most 11 rows and arms up to 13 / 15, its shape --
+// byte 0 = up | down << 4, bytes 1 .. = left | right << 4 per row -- so that no arm length is looked up; byte 0 = 0xff: look them
+// up.  Runs are read four values at a time (any 4-byte alignment), the values behind a run's end add -0.0f (x + -0.0f == x).
+__device__ __forceinline__ void list_phase(const LeanArgs &A, long long w, int d, int lane)
+{
+	const int W = A.W, HWi = A.H * A.W;
+	const int sh = d * A.direction;
+	const cb_u32 OOB = 0x80000000u;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
+	const uint32_t *__restrict__ slots = A.hdr + A.slots_words;
+	cb_u32 seg = A.hdr[A.wtab_words + 2 * w];   // slot + 1 of the wave's first segment
+	seg = (cb_u32)__builtin_amdgcn_readfirstlane((int)seg);
+	int guard = 0;
+	while (seg != 0 && seg <= A.cap && ++guard < (1 << 20)) {
+		const cb_u4 sh4 = *(const cb_u4 *)(slots + (size_t)(seg - 1) * 4);   // segment header: {entries, next segment's slot + 1}
+		const int n = min((int)__builtin_amdgcn_readfirstlane((int)sh4.x), (int)(A.cap - (seg - 1)) - 1);
+		const cb_u32 next = (cb_u32)__builtin_amdgcn_readfirstlane((int)sh4.y);
+		for (int i = lane; i < n; i += 64) {
+			const cb_u4 e = *(const cb_u4 *)(slots + (size_t)(seg + i) * 4);
+			const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;
+			if (rem >= (cb_u32)HWi) continue;   // (not this plane's: never written by cbca_classify_kernel)
+			const int y = (int)(rem / (cb_u32)W), x = (int)(rem - (cb_u32)y * (cb_u32)W);
+			const cb_u32 b0 = e.y & 0xffu;
+			float sum = 0;
+			int cnt = 0;
+			if (b0 != 0xffu) {
+				const int u = (int)(b0 & 15u), rows = u + (int)(b0 >> 4) + 1;
+				for (int k = 0; k < rows; ++k) {
+					const cb_u32 lr = entry_byte(e, 1 + k);
+					const int l = (int)(lr & 15u), nn = l + (int)(lr >> 4) + 1;
+					const int start = (y - u + k) * W + x - l;
+					for (int c = 0; c < nn; c += 4) {
+						const cb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rv, (cb_u32)(start + c) * 4u, 0, 0);
+						sum += __uint_as_float(v.x);
+						sum += c + 1 < nn ? __uint_as_float(v.y) : -0.0f;
+						sum += c + 2 < nn ? __uint_as_float(v.z) : -0.0f;
+						sum += c + 3 < nn ? __uint_as_float(v.w) : -0.0f;
+					}
+					cnt += nn;
+				}
+			} else {
+				const uint32_t mm = bytemin4(A.p0[y * W + x], A.p1[y * W + x + sh]);
+				const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
+				for (int q = y - u; q <= y + dn; ++q) {
+					const int g = q * W + x;
+					const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
+					const int l = (int)(m & 0xffu), nn = l + (int)((m >> 8) & 0xffu) + 1;
+					for (int k = 0; k < nn; ++k) sum += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, (cb_u32)(g - l + k) * 4u, 0, 0));
+					cnt += nn;
+				}
+			}
+			A.vout[(size_t)d * HWi + rem] = sum / (float)cnt;
+		}
+		seg = next;
+	}
+	(void)OOB;
+}
+
 }  // namespace
 
 // ---- once per pair and direction: the outputs the lean kernel gets wrong ---------------------------------------------------
 // An output (d, y, x) with a partner has the minimal support iff its combined arms (per-arm minimum of the two images,
 // cbca.hip "Packed arm lengths") are all 1 and the rows above and below have left = right = 1 in its column -- the test of
-// the strip kernel.  Everything else with a partner is listed.  Entries are collected per wave in LDS and appended 256 and
-// more at a time (one atomic per flush).
+// the strip kernel.  Everything else with a partner is listed.  The waves are the lean kernel's (same plane, rows, strip): a
+// wave collects its entries in LDS and appends them 256 and more at a time as a SEGMENT -- one atomic for its slots, a header
+// slot {entries, next segment}, the entries with their supports' shapes (looked up here, once per pair, instead of in every
+// pass) -- chained from the wave's word of the wave table.
 __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 {
 	__shared__ cb_u32 bufs[4][512];
@@ -62,12 +134,13 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	cb_u32 *__restrict__ buf = bufs[wv];
-	if (blockIdx.x == 0 && threadIdx.x == 0) {   // (the count and the overflow word were zeroed by the host's memset)
+	if (blockIdx.x == 0 && threadIdx.x == 0) {   // (count, overflow word and wave table were zeroed by the host's memset)
 		A.hdr[LH_D] = (uint32_t)A.D; A.hdr[LH_H] = (uint32_t)A.H; A.hdr[LH_W] = (uint32_t)A.W;
-		A.hdr[LH_DIR] = (uint32_t)(A.direction + 1); A.hdr[LH_MAGIC] = LH_MAGIC_VALUE;
+		A.hdr[LH_DIR] = (uint32_t)(A.direction + 1); A.hdr[LH_RB] = (uint32_t)A.rb; A.hdr[LH_MAGIC] = LH_MAGIC_VALUE;
 	}
+	long long w;
 	int d, y0, y1, xb;
-	if (!lean_wave(A, wv, d, y0, y1, xb)) return;
+	if (!lean_wave(A, wv, w, d, y0, y1, xb)) return;
 	const int H = A.H, W = A.W;
 	const int HWi = H * W;
 	const int sh = d * A.direction;
@@ -89,14 +162,44 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 		const cb_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
 		m[0] = bytemin4(a.x, b.x); m[1] = bytemin4(a.y, b.y); m[2] = bytemin4(a.z, b.z); m[3] = bytemin4(a.w, b.w);
 	};
+	uint32_t *__restrict__ slots = A.hdr + A.slots_words;
 	int cnt = 0;
+	cb_u32 prev = 0;   // slot + 1 of this wave's last segment header
 	auto flush = [&]() {
 		cb_u32 base = 0;
-		if (lane == 0) base = atomicAdd(A.hdr + LH_COUNT, (cb_u32)cnt);
+		if (lane == 0) base = atomicAdd(A.hdr + LH_COUNT, (cb_u32)cnt + 1u);
 		base = (cb_u32)__builtin_amdgcn_readfirstlane((int)base);
+		if (base + (cb_u32)cnt + 1u > A.cap) {   // the list does not fit: the passes fall back to the strip kernel
+			if (lane == 0) A.hdr[LH_OVERFLOW] = 1u;
+			cnt = 0;
+			return;
+		}
+		if (lane == 0) {
+			*(cb_u4 *)(slots + (size_t)base * 4) = cb_u4{(cb_u32)cnt, 0u, 0u, 0u};
+			if (prev) slots[(size_t)(prev - 1) * 4 + 1] = base + 1u;
+			else A.hdr[A.wtab_words + 2 * w] = base + 1u;
+		}
+		prev = base + 1u;
 		for (int i = lane; i < cnt; i += 64) {
-			if (base + (cb_u32)i < A.cap) A.hdr[LH_WORDS + base + i] = buf[i];
-			else A.hdr[LH_OVERFLOW] = 1u;   // (the list does not fit: the passes fall back to the strip kernel)
+			const cb_u32 idx = buf[i];
+			const cb_u32 rem = idx - (cb_u32)d * (cb_u32)HWi;
+			const int y = (int)(rem / (cb_u32)W), x = (int)(rem - (cb_u32)y * (cb_u32)W);
+			const uint32_t mm = bytemin4(A.p0[y * W + x], A.p1[y * W + x + sh]);
+			const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
+			const int rows = u + dn + 1;
+			bool fits = u <= 13 && dn <= 13 && rows <= 11;
+			cb_u32 ew[3] = {(cb_u32)(u | (dn << 4)), 0u, 0u};
+			for (int k = 0; k < rows && fits; ++k) {
+				const int g = (y - u + k) * W + x;
+				const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
+				const cb_u32 l = m & 0xffu, r = (m >> 8) & 0xffu;
+				fits = l <= 15u && r <= 15u;
+				const int j = 1 + k;
+				const cb_u32 byte = (l | (r << 4)) << ((j & 3) * 8);
+				if (j < 4) ew[0] |= byte; else if (j < 8) ew[1] |= byte; else ew[2] |= byte;
+			}
+			if (!fits) { ew[0] = 0xffu; ew[1] = ew[2] = 0u; }
+			*(cb_u4 *)(slots + (size_t)(base + 1 + i) * 4) = cb_u4{idx, ew[0], ew[1], ew[2]};
 		}
 		cnt = 0;
 	};
@@ -129,17 +232,18 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 // (lines the neighbouring strips read anyway).  Nine additions per output in the reference's order -- rows ascending, x
 // ascending, accumulator starting at +0.0 (adcensus.cu:356-373) -- and an IEEE divide by 9; outputs without a partner are
 // copied through.  What is wrong afterwards -- outputs with another support, among them every output on the image border,
-// where the window reads zeros -- is exactly what cbca_classify_kernel listed.
-template <int PF, bool NT>
+// where the window reads zeros -- is exactly what cbca_classify_kernel listed for this wave: list_phase overwrites them.
+template <int PF, bool NT, bool INLINE_LIST>
 __global__ void __launch_bounds__(256) cbca_lean_kernel(const LeanArgs A)
 {
 	static_assert(PF % 3 == 0, "the neighbour columns of the three-row window rotate by renaming");
 	constexpr int AUX = NT ? 2 : 0;   // volumes far beyond the 256 MB Infinity Cache are streamed (cbca_strip_kernel)
-	if (!cbca_gate(A.flags, A.route) || !list_valid(A.hdr, A.D, A.H, A.W, A.direction)) return;
+	if (!cbca_gate(A.flags, A.route) || !lean_list_valid(A)) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	long long w;
 	int d, y0, y1, xb;
-	if (!lean_wave(A, wv, d, y0, y1, xb)) return;
+	if (!lean_wave(A, wv, w, d, y0, y1, xb)) return;
 	const int H = A.H, W = A.W;
 	const int HWi = H * W;
 	const int sh = d * A.direction;
@@ -189,11 +293,12 @@ __global__ void __launch_bounds__(256) cbca_lean_kernel(const LeanArgs A)
 			asm volatile("" : "+v"(q));   // (computed for every lane: otherwise the divide becomes a conditional block)
 			res[j] = ((inr >> j) & 1u) ? q : rb_[j + 1];
 		}
-		const bool mine = (yo >= y0) & (yo < y1) & lane_in;
+		const bool myrow = (yo >= y0) & (yo < y1);
 		// stored through a descriptor that ends with the row: the words of a last unit beyond the image are dropped by the range check
-		const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, (yo + 1) * W * 4, 0x00020000);
+		// (and an empty one for the staged rows that complete no output row of this wave: nothing may pass the check there)
+		const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, myrow ? (yo + 1) * W * 4 : 0, 0x00020000);
 		__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
-		                                       rrow, mine ? (cb_u32)(yo * W + xs) * 4u : OOB, 0, AUX);
+		                                       rrow, (myrow & lane_in) ? (cb_u32)(yo * W + xs) * 4u : OOB, 0, AUX);
 	};
 	const int ra = y0 - 1;   // first staged row; rows ra .. y1 are staged, row r completes the window of output row r - 1
 	for (int g = ra - PF; g <= y1; g += U) {
@@ -208,67 +313,70 @@ __global__ void __launch_bounds__(256) cbca_lean_kernel(const LeanArgs A)
 			__builtin_amdgcn_sched_barrier(0);   // (rows stay in program order: hoisted additions of later rows would wait for their loads early)
 		}
 	}
-}
-
-// ---- per pass: the listed outputs, one thread per entry: the reference's loop (rows ascending, x ascending, one accumulator) ----
-__global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
-{
-	if (!cbca_gate(A.flags, A.route) || !list_valid(A.hdr, A.D, A.H, A.W, A.direction)) return;
-	const uint32_t n = min(A.hdr[LH_COUNT], A.cap);
-	const uint32_t W = (uint32_t)A.W, HW = (uint32_t)A.H * (uint32_t)A.W;
-	const uint32_t *__restrict__ ent = A.hdr + LH_WORDS;
-	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-		const uint32_t idx = ent[i];
-		const uint32_t d = idx / HW, rem = idx - d * HW;
-		const int y = (int)(rem / W), x = (int)(rem - (uint32_t)y * W);
-		const int sh = (int)d * A.direction;
-		const float *__restrict__ vd = A.vin + (size_t)d * HW;
-		const uint32_t mm = bytemin4(A.p0[y * (int)W + x], A.p1[y * (int)W + x + sh]);
-		const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
-		float sum = 0;
-		int cnt = 0;
-		for (int q = y - u; q <= y + dn; ++q) {
-			const int g = q * (int)W + x;
-			const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
-			const int l = (int)(m & 0xffu), nn = l + (int)((m >> 8) & 0xffu) + 1;
-			const float *__restrict__ row = vd + g - l;
-			for (int k = 0; k < nn; ++k) sum += row[k];
-			cnt += nn;
-		}
-		A.vout[idx] = sum / (float)cnt;
+	if (INLINE_LIST) {
+		// the wave's listed outputs, after its own stores have completed (the same addresses are written again, by other lanes)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		list_phase(A, w, d, lane);
 	}
 }
 
+// ... the listed outputs in a launch of their own (one wave per wave of the lean kernel): the form the inline one is measured against
+__global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
+{
+	if (!cbca_gate(A.flags, A.route) || !lean_list_valid(A)) return;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	long long w;
+	int d, y0, y1, xb;
+	if (!lean_wave(A, wv, w, d, y0, y1, xb)) return;
+	list_phase(A, w, d, lane);
+}
+
+
 static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
-                          int route, int rb)
+                          int route, int rb, int cap_limit = 0)
 {
 	LeanArgs A;
 	const CbcaScratch cs = cbca_scratch(packed, H, W);
 	A.p0 = cs.p0; A.p1 = cs.p1;
 	A.vin = vin; A.vout = vout;
 	A.hdr = (uint32_t *)plan;
-	A.cap = (uint32_t)std::min<size_t>((plan_bytes - LH_WORDS * 4) / 4, 0xfffffff0u);
 	A.D = D; A.H = H; A.W = W; A.direction = direction;
 	A.gx = (int)cdiv(W, 256);
 	// rows per wave: 2 / rb of the rows are read twice; at least ~12 K waves
 	const int64_t gy_min = cdiv((int64_t)12288, (int64_t)A.gx * D);
 	A.rb = rb > 0 ? rb : (int)std::min<int64_t>(128, std::max<int64_t>(16, cdiv((int64_t)H, gy_min)));
 	A.gy = (int)cdiv(H, A.rb);
+	const int64_t waves = (int64_t)A.gx * A.gy * D;
+	A.wtab_words = LH_WORDS;
+	A.slots_words = (uint32_t)((LH_WORDS + 2 * waves + 3) / 4 * 4);
+	const int64_t room = (int64_t)plan_bytes / 4 - A.slots_words;
+	A.cap = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(room / 4, 0x3ffffff0));
+	if (cap_limit > 0) A.cap = std::min(A.cap, (uint32_t)cap_limit);   // (test hook: a list that does not fit)
 	A.flags = cs.flag;
 	A.route = route;
 	return A;
 }
 
+// rows per wave of the lean / classify kernels for a problem (rb > 0: forced): the list is valid for this value only
+int cbca_lean_rows(int D, int H, int W, int rb)
+{
+	return lean_args(nullptr, nullptr, 0, nullptr, nullptr, D, H, W, -1, 0, rb).rb;
+}
+
 bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes)
 {
-	return (int64_t)D * H * W < ((int64_t)1 << 32) && plan_bytes > (size_t)LH_WORDS * 4;
+	if ((int64_t)D * H * W >= ((int64_t)1 << 32)) return false;   // (32-bit voxel indices in the entries)
+	const LeanArgs A = lean_args(nullptr, nullptr, plan_bytes, nullptr, nullptr, D, H, W, -1, 0, 0);
+	return A.cap >= 2 && (int64_t)A.gx * A.gy * D < ((int64_t)1 << 30);
 }
 
 // once per pair and direction (before the first pass): the list of outputs whose support is not the minimal 3 x 3
-int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, hipStream_t st)
+int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, int rb, int cap_limit,
+                  hipStream_t st)
 {
-	const LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, 0);
-	const hipError_t e = hipMemsetAsync(plan, 0, LH_WORDS * 4, st);
+	const LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb, cap_limit);
+	const hipError_t e = hipMemsetAsync(plan, 0, (size_t)A.slots_words * 4, st);   // header + wave table
 	if (e != hipSuccess) {
 		set_error("cbca_classify: %s", hipGetErrorString(e));
 		return (int)e;
@@ -278,27 +386,32 @@ int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int 
 	return check_launch("cbca_classify");
 }
 
-// one aggregation pass: the lean kernel over every output, then the listed outputs
+// one aggregation pass: the lean kernel over every output + the listed outputs (cfg.variant: bits 0-1 rows in flight 6 / 3 / 9,
+// bit 2 the listed outputs in a launch of their own)
 int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
               int route, hipStream_t st, const CbcaCfg &cfg)
 {
-	const LeanArgs A = lean_args(packed, (void *)plan, plan_bytes, vin, vout, D, H, W, direction, route, cfg.rb);
+	const LeanArgs A = lean_args(packed, (void *)plan, plan_bytes, vin, vout, D, H, W, direction, route, cfg.rb, cfg.nd);
 	const int64_t waves = (int64_t)A.gx * A.gy * D;
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)D * H * W * 4 > ((int64_t)768 << 20);
 	const unsigned blocks = (unsigned)cdiv(waves, 4);
-	if (cfg.variant == 1) {
-		if (nt) hipLaunchKernelGGL((cbca_lean_kernel<3, true>), dim3(blocks), dim3(256), 0, st, A);
-		else hipLaunchKernelGGL((cbca_lean_kernel<3, false>), dim3(blocks), dim3(256), 0, st, A);
-	} else if (cfg.variant == 2) {
-		if (nt) hipLaunchKernelGGL((cbca_lean_kernel<9, true>), dim3(blocks), dim3(256), 0, st, A);
-		else hipLaunchKernelGGL((cbca_lean_kernel<9, false>), dim3(blocks), dim3(256), 0, st, A);
-	} else {
-		if (nt) hipLaunchKernelGGL((cbca_lean_kernel<6, true>), dim3(blocks), dim3(256), 0, st, A);
-		else hipLaunchKernelGGL((cbca_lean_kernel<6, false>), dim3(blocks), dim3(256), 0, st, A);
-	}
+	const bool own_launch = (cfg.variant & 4) != 0;
+	const int pf = cfg.variant & 3;
+#define MC_LEAN_LAUNCH(PF) do { \
+		if (own_launch) { \
+			if (nt) hipLaunchKernelGGL((cbca_lean_kernel<PF, true, false>), dim3(blocks), dim3(256), 0, st, A); \
+			else hipLaunchKernelGGL((cbca_lean_kernel<PF, false, false>), dim3(blocks), dim3(256), 0, st, A); \
+		} else { \
+			if (nt) hipLaunchKernelGGL((cbca_lean_kernel<PF, true, true>), dim3(blocks), dim3(256), 0, st, A); \
+			else hipLaunchKernelGGL((cbca_lean_kernel<PF, false, true>), dim3(blocks), dim3(256), 0, st, A); \
+		} } while (0)
+	if (pf == 1) MC_LEAN_LAUNCH(3);
+	else if (pf == 2) MC_LEAN_LAUNCH(9);
+	else MC_LEAN_LAUNCH(6);
+#undef MC_LEAN_LAUNCH
 	int rc = check_launch("cbca_lean");
-	if (rc) return rc;
-	hipLaunchKernelGGL(cbca_list_kernel, dim3(2048), dim3(256), 0, st, A);
+	if (rc || !own_launch) return rc;
+	hipLaunchKernelGGL(cbca_list_kernel, dim3(blocks), dim3(256), 0, st, A);
 	return check_launch("cbca_list");
 }
 

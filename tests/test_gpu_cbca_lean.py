@@ -48,7 +48,7 @@ def test_lean_and_list(mc, oracle, H, W, D, mk, L1, tau1):
 
 
 @pytest.mark.parametrize("rb", [1, 2, 3, 7, 16, 64])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 6])   # bits 0-1: rows in flight 6 / 3 / 9, bit 2: the listed outputs in a launch of their own
 def test_lean_rows_per_wave_and_prefetch_depth(mc, oracle, rb, variant):
     H, W, D = 61, 530, 5
     x0, x1 = smooth_pair(H, W, 8, seed=3)
@@ -89,8 +89,8 @@ def test_lean_special_values(mc, oracle):
 
 def test_lean_falls_back_to_the_strip_kernel(mc, oracle):
     """(a) a list written for another problem (other direction / other shape on the same cached scratch) is not used;
-    (b) a list that cannot hold the pair's entries (the hook's nd = capacity in entries; in mc_predict the plan area always can)
-    -- the strip kernel runs instead, results stay exact"""
+    (b) a list that cannot hold the pair's entries (the hook's nd = capacity in 16-byte slots), (c) a list written for other rows
+    per wave -- the strip kernel runs instead, results stay exact"""
     H, W, D = 33, 140, 4
     x0, x1 = smooth_pair(H, W, 8, seed=2)
     x0c, x1c = oracle.cross(x0, 14, 0.05), oracle.cross(x1, 14, 0.05)
@@ -101,6 +101,12 @@ def test_lean_falls_back_to_the_strip_kernel(mc, oracle):
     mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vr), out, 1, form=9)     # the list on the scratch is direction -1's
     got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, vr, 1)
     assert same_bits(got, want), diff_report(got, want, "list of the other direction")
+    out = torch.full((1, D, H, W), -7.0, device="cuda")
+    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=7, form=8)
+    out = torch.full((1, D, H, W), -7.0, device="cuda")
+    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=9, form=9)   # the list on the scratch was written for 7 rows per wave
+    got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, vl, -1)
+    assert same_bits(got, want), diff_report(got, want, "list of another wave geometry")
     for Hf, Wf, Df in ((64, 300, 2), (200, 600, 1)):
         z = np.zeros((Hf, Wf), np.float32)
         zc = oracle.cross(z, 14, 1.0)
