@@ -97,8 +97,9 @@ def config_key(cfg):
     return next(k for k, v in CONFIGS.items() if v is cfg or v == cfg)
 
 
-def make_inputs(cfg, rank, device, pair=None):
-    import torch
+def make_inputs(cfg, rank, device, pair=None, raw_planes=None):
+    """This rank's inputs (device = None: host arrays only).  Seeds: images 1234 + rank (synthetic pairs), features 42 + rank,
+    raw volumes 7 + rank -- BASELINE configs[4] is "8 Middlebury-size pairs, seeds 7 ... 14", one per GPU."""
     from util import features, natural_pair, raw_volumes, sample_pair, smooth_pair
     preset, H, W, D, C, _ = cfg
     pair = pair or PAIR_OF[config_key(cfg)]
@@ -106,25 +107,31 @@ def make_inputs(cfg, rank, device, pair=None):
         x0, x1 = sample_pair(H, W)
     else:
         x0, x1 = (natural_pair if pair == "natural" else smooth_pair)(H, W, D, seed=1234 + rank)
-    xb = torch.from_numpy(np.stack([x0, x1])[:, None]).to(device)
-    host = dict(x0=x0, x1=x1)
+    host = dict(x0=x0, x1=x1, seeds=dict(images=None if pair == "sample" else 1234 + rank))
     if C < 0:  # accurate net: non-negative (post-ReLU) features + a seeded FC stack (no trained nets are available)
-        from mc_cnn_amd.main import load_fc
         rng = np.random.default_rng(42 + rank)
-        f = np.maximum(rng.standard_normal((2, -C, H, W)), 0).astype(np.float32)
-        host["feat"] = f
+        host["feat"] = np.maximum(rng.standard_normal((2, -C, H, W)), 0).astype(np.float32)
+        host["seeds"].update(features=42 + rank, fc_stack=7 + rank)
+    elif C:
+        host["feat"] = features(C, H, W, seed=42 + rank)
+        host["seeds"].update(features=42 + rank)
+    else:
+        host["raw"] = raw_volumes(raw_planes or D, H, W, seed=7 + rank)   # (raw_planes: --dry-run fingerprints the left volume's first planes only)
+        host["seeds"].update(raw_volumes=7 + rank)
+    if device is None:
+        return None, None, host
+    import torch
+    xb = torch.from_numpy(np.stack([x0, x1])[:, None]).to(device)
+    if C < 0:
+        from mc_cnn_amd.main import load_fc
         fcl = load_fc("random:%d" % (7 + rank), "kitti")
-        kw = dict(fc_feat=torch.from_numpy(f).to(device),
+        kw = dict(fc_feat=torch.from_numpy(host["feat"]).to(device),
                   fc_layers=[(torch.from_numpy(w).to(device), torch.from_numpy(b).to(device)) for w, b in fcl])
         host["fc_layers"] = fcl
     elif C:
-        f = features(C, H, W, seed=42 + rank)
-        host["feat"] = f
-        kw = dict(feat=torch.from_numpy(f).to(device))
+        kw = dict(feat=torch.from_numpy(host["feat"]).to(device))
     else:
-        vl, vr = raw_volumes(D, H, W, seed=7 + rank)
-        host["raw"] = (vl, vr)
-        kw = dict(raw=(torch.from_numpy(vl).to(device), torch.from_numpy(vr).to(device)))
+        kw = dict(raw=(torch.from_numpy(host["raw"][0]).to(device), torch.from_numpy(host["raw"][1]).to(device)))
     return xb, kw, host
 
 
@@ -558,10 +565,11 @@ def main():
         import hashlib
         rank = int(os.environ.get("RANK", "0"))
         cfg = CONFIGS[args.config]
-        _, _, host = make_inputs(cfg, rank, "cpu", args.pair or PAIR_OF[args.config])
-        fp = {k: hashlib.sha1(np.ascontiguousarray(v if not isinstance(v, tuple) else v[0]).tobytes()).hexdigest()[:16]
-              for k, v in host.items() if k in ("x0", "x1", "raw", "feat")}
-        print(json.dumps(dict(config=args.config, rank=rank, gpus=args.gpus, inputs=fp, cpus=rank_cpus(rank, args.gpus))))
+        _, _, host = make_inputs(cfg, rank, None, args.pair or PAIR_OF[args.config], raw_planes=2)
+        fp = {k: hashlib.sha1(np.ascontiguousarray(v if not isinstance(v, tuple) else v[0][:2]).tobytes()).hexdigest()[:16]
+              for k, v in host.items() if k in ("x0", "x1", "raw", "feat")}   # (raw volumes: the first two planes of the left one)
+        print(json.dumps(dict(config=args.config, workload=cfg[5], rank=rank, gpus=args.gpus, seeds=host["seeds"], inputs=fp,
+                              cpus=rank_cpus(rank, args.gpus))))
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

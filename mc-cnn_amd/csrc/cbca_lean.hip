@@ -60,9 +60,12 @@ __device__ __forceinline__ cb_u32 entry_byte(const cb_u4 &e, int j)
 }
 
 // The wave's listed outputs: the reference's loop (rows ascending, x ascending, one accumulator, adcensus.cu:356-373), one lane
-// per entry.  An entry holds the voxel index and, where the support has at most 11 rows and arms up to 13 / 15, its shape --
-// byte 0 = up | down << 4, bytes 1 .. = left | right << 4 per row -- so that no arm length is looked up; byte 0 = 0xff: look them
-// up.  Runs are read four values at a time (any 4-byte alignment), the values behind a run's end add -0.0f (x + -0.0f == x).
+// per entry.  An entry holds the voxel index and its support's shape, so that no arm length is looked up in a pass:
+//   byte 0 = 0xe0 | up | down << 2      at most four rows of at most four values each (99.8 % of a texture's entries): bytes 1 .. 4 =
+//                                       left | right << 4 per row; the four runs are requested at once, one 16-byte load each
+//   byte 0 = up | down << 4 (< 0xe0)    at most 11 rows, arms up to 13 / 15: bytes 1 .. 11 = left | right << 4 per row
+//   byte 0 = 0xff                       anything else: the arm lengths are looked up
+// Runs are read four values at a time (any 4-byte alignment); the values behind a run's end add -0.0f (x + -0.0f == x).
 __device__ __forceinline__ void list_phase(const LeanArgs &A, long long w, int d, int lane)
 {
 	const int W = A.W, HWi = A.H * A.W;
@@ -79,43 +82,59 @@ __device__ __forceinline__ void list_phase(const LeanArgs &A, long long w, int d
 		const cb_u32 next = (cb_u32)__builtin_amdgcn_readfirstlane((int)sh4.y);
 		for (int i = lane; i < n; i += 64) {
 			const cb_u4 e = *(const cb_u4 *)(slots + (size_t)(seg + i) * 4);
-			const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;
+			const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;   // y * W + x
 			if (rem >= (cb_u32)HWi) continue;   // (not this plane's: never written by cbca_classify_kernel)
-			const int y = (int)(rem / (cb_u32)W), x = (int)(rem - (cb_u32)y * (cb_u32)W);
 			const cb_u32 b0 = e.y & 0xffu;
 			float sum = 0;
 			int cnt = 0;
-			if (b0 != 0xffu) {
+			if ((b0 & 0xf0u) == 0xe0u) {
+				const int u = (int)(b0 & 3u), rows = u + (int)((b0 >> 2) & 3u) + 1;
+				cb_u4 v[4];
+				int nn[4];
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const cb_u32 lr = entry_byte(e, 1 + k);
+					nn[k] = k < rows ? (int)(lr & 15u) + (int)(lr >> 4) + 1 : 0;
+					v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, k < rows ? (cb_u32)((int)rem + (k - u) * W - (int)(lr & 15u)) * 4u : OOB, 0, 0);
+				}
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					sum += 0 < nn[k] ? __uint_as_float(v[k].x) : -0.0f;
+					sum += 1 < nn[k] ? __uint_as_float(v[k].y) : -0.0f;
+					sum += 2 < nn[k] ? __uint_as_float(v[k].z) : -0.0f;
+					sum += 3 < nn[k] ? __uint_as_float(v[k].w) : -0.0f;
+					cnt += nn[k];
+				}
+			} else if (b0 != 0xffu) {
 				const int u = (int)(b0 & 15u), rows = u + (int)(b0 >> 4) + 1;
 				for (int k = 0; k < rows; ++k) {
 					const cb_u32 lr = entry_byte(e, 1 + k);
-					const int l = (int)(lr & 15u), nn = l + (int)(lr >> 4) + 1;
-					const int start = (y - u + k) * W + x - l;
-					for (int c = 0; c < nn; c += 4) {
+					const int l = (int)(lr & 15u), nk = l + (int)(lr >> 4) + 1;
+					const int start = (int)rem + (k - u) * W - l;
+					for (int c = 0; c < nk; c += 4) {
 						const cb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rv, (cb_u32)(start + c) * 4u, 0, 0);
 						sum += __uint_as_float(v.x);
-						sum += c + 1 < nn ? __uint_as_float(v.y) : -0.0f;
-						sum += c + 2 < nn ? __uint_as_float(v.z) : -0.0f;
-						sum += c + 3 < nn ? __uint_as_float(v.w) : -0.0f;
+						sum += c + 1 < nk ? __uint_as_float(v.y) : -0.0f;
+						sum += c + 2 < nk ? __uint_as_float(v.z) : -0.0f;
+						sum += c + 3 < nk ? __uint_as_float(v.w) : -0.0f;
 					}
-					cnt += nn;
+					cnt += nk;
 				}
 			} else {
-				const uint32_t mm = bytemin4(A.p0[y * W + x], A.p1[y * W + x + sh]);
+				const uint32_t mm = bytemin4(A.p0[rem], A.p1[(int)rem + sh]);
 				const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
-				for (int q = y - u; q <= y + dn; ++q) {
-					const int g = q * W + x;
+				for (int q = -u; q <= dn; ++q) {
+					const int g = (int)rem + q * W;
 					const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
-					const int l = (int)(m & 0xffu), nn = l + (int)((m >> 8) & 0xffu) + 1;
-					for (int k = 0; k < nn; ++k) sum += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, (cb_u32)(g - l + k) * 4u, 0, 0));
-					cnt += nn;
+					const int l = (int)(m & 0xffu), nk = l + (int)((m >> 8) & 0xffu) + 1;
+					for (int k = 0; k < nk; ++k) sum += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, (cb_u32)(g - l + k) * 4u, 0, 0));
+					cnt += nk;
 				}
 			}
 			A.vout[(size_t)d * HWi + rem] = sum / (float)cnt;
 		}
 		seg = next;
 	}
-	(void)OOB;
 }
 
 }  // namespace
@@ -182,23 +201,25 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 		prev = base + 1u;
 		for (int i = lane; i < cnt; i += 64) {
 			const cb_u32 idx = buf[i];
-			const cb_u32 rem = idx - (cb_u32)d * (cb_u32)HWi;
-			const int y = (int)(rem / (cb_u32)W), x = (int)(rem - (cb_u32)y * (cb_u32)W);
-			const uint32_t mm = bytemin4(A.p0[y * W + x], A.p1[y * W + x + sh]);
+			const int rem = (int)(idx - (cb_u32)d * (cb_u32)HWi);   // y * W + x
+			const uint32_t mm = bytemin4(A.p0[rem], A.p1[rem + sh]);
 			const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
 			const int rows = u + dn + 1;
 			bool fits = u <= 13 && dn <= 13 && rows <= 11;
-			cb_u32 ew[3] = {(cb_u32)(u | (dn << 4)), 0u, 0u};
+			bool small = rows <= 4;   // at most four rows of at most four values
+			cb_u32 ew[3] = {0u, 0u, 0u};
 			for (int k = 0; k < rows && fits; ++k) {
-				const int g = (y - u + k) * W + x;
+				const int g = rem + (k - u) * W;
 				const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
 				const cb_u32 l = m & 0xffu, r = (m >> 8) & 0xffu;
 				fits = l <= 15u && r <= 15u;
+				small = small && l + r <= 3u;
 				const int j = 1 + k;
 				const cb_u32 byte = (l | (r << 4)) << ((j & 3) * 8);
 				if (j < 4) ew[0] |= byte; else if (j < 8) ew[1] |= byte; else ew[2] |= byte;
 			}
 			if (!fits) { ew[0] = 0xffu; ew[1] = ew[2] = 0u; }
+			else ew[0] |= small ? (0xe0u | (cb_u32)u | ((cb_u32)dn << 2)) : (cb_u32)(u | (dn << 4));
 			*(cb_u4 *)(slots + (size_t)(base + 1 + i) * 4) = cb_u4{idx, ew[0], ew[1], ew[2]};
 		}
 		cnt = 0;

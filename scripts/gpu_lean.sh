@@ -16,3 +16,4 @@ try:
     j=json.load(open("$O/bench_mb_slow.json")); print("mb_slow", j["ms_per_step"], j["stage_ms"], j["roofline"]["frac"], j["verify"]["bit_exact"])
 except Exception as e: print("bench failed", e); print(open("$O/bench_mb_slow.err").read()[-1500:])
 PY
+if [ "$3" = prof ]; then bash scripts/gpu_prof.sh $TAG mb_slow 2; fi

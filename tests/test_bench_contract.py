@@ -37,7 +37,8 @@ def test_workloads_are_baseline_configs():
     assert b.CONFIGS["mb_slow"][1:4] == (1000, 1500, 256) and "1500x1000" in base["configs"][3]
     assert b.HBM_PEAK_GBS == 8000.0
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'default="kitti_fast"' in src          # BASELINE configs[1] is what `python bench.py` measures
+    # BASELINE configs[1] is what `python bench.py` measures on one GPU, configs[4] (a Middlebury-size pair per rank) on several
+    assert 'args.config = "kitti_fast" if args.gpus <= 1 else "mb_slow"' in src
     assert base["metric"].startswith("Mega-pixel-disparities/sec")
 
 
@@ -89,3 +90,29 @@ def test_support_sizes_count_the_taps_of_the_reference_loop(oracle):
                 l, r, u, dn = m[:, y, x]
                 want = sum(int(m[0, q, x] + m[1, q, x] + 1) for q in range(y - u, y + dn + 1))
                 assert size[y, x] == want
+
+
+def test_multi_gpu_default_is_configs4_with_per_rank_pairs():
+    """`bench.py --gpus N` (N > 1) measures BASELINE configs[4]: one Middlebury-size accurate pair per GPU, every rank its own
+    seeded pair -- checked without a GPU through --dry-run (the inputs a rank would process, fingerprinted)"""
+    import subprocess, sys
+    recs = []
+    for r in (0, 1):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        recs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "Middlebury-size" in base["configs"][4]
+    for r, rec in enumerate(recs):
+        assert rec["config"] == "mb_slow" and rec["rank"] == r and "1000x1500" in rec["workload"]
+        assert rec["seeds"] == {"images": 1234 + r, "raw_volumes": 7 + r}          # configs[4]: seeds 7 ... 14, one per GPU
+    for k in ("x0", "x1", "raw"):
+        assert recs[0]["inputs"][k] != recs[1]["inputs"][k], "both ranks would process the same %s" % k
+    if recs[0]["cpus"] and recs[1]["cpus"]:   # disjoint shares of the host cores
+        assert not set(recs[0]["cpus"]) & set(recs[1]["cpus"])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--config", "tiny"], capture_output=True, text=True, timeout=600)
+    assert json.loads(one.stdout.strip().splitlines()[-1])["config"] == "tiny"
+    d = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=600)
+    assert json.loads(d.stdout.strip().splitlines()[-1])["config"] == "kitti_fast"   # one GPU: BASELINE configs[1]
