@@ -37,7 +37,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define MC_ABI_VERSION 6
+#define MC_ABI_VERSION 7
 #define MC_EINVAL (-22)
 #define MC_SGM_MAX_D 512   /* reference: __shared__ float[400], adcensus.cu:574 */
 #define MC_JOIN_MAX_C 128  /* reference: float L_cache[128], adcensus.cu:1460-1461 */
@@ -263,6 +263,21 @@ int mc_predict_timed(const mc_params *p, const float *x0, const float *x1,
                      void *workspace, size_t workspace_bytes, float *disp_out, void *stream,
                      float *stage_ms);
 
+/* ---- host side of libadcensus: submission / ground-truth image formats -------------------------------------------------
+ * HOST pointers (the reference takes torch.FloatTensor here), no device, no stream.  16-bit greyscale PNG through a codec
+ * written against the PNG specification on zlib (png++ / libpng, which the reference links, have no headers in the build
+ * image); 8-bit greyscale files are accepted on read (v * 257). */
+
+/* adcensus.readPNG16(img, fname), adcensus.cu:1670-1686: img[y * width + x] = val == 0 ? 0 : val / 256 (float).
+ * *height, *width receive the file's size; img == NULL: size query only; capacity = floats img can hold. */
+int mc_read_png16(const char *fname, float *img, int64_t capacity, int *height, int *width);
+
+/* adcensus.writePNG16(img, height, width, fname), adcensus.cu:1688-1704: pixel = (uint16_t)(val < 1e-5 ? 0 : val * 256). */
+int mc_write_png16(const float *img, int height, int width, const char *fname);
+
+/* adcensus.writePFM(img, fname), adcensus.cu:1706-1721: "Pf", "width height", scale -0.003922, rows as stored, raw floats. */
+int mc_write_pfm(const float *img, int height, int width, const char *fname);
+
 /* ---- test / bench hooks (not part of the reference's surface) ---------------- */
 
 /* mc_cbca_ws with the launch configuration forced instead of derived from the problem: cache policy `nt` (-1 = auto,
@@ -273,6 +288,10 @@ int mc_predict_timed(const mc_params *p, const float *x0, const float *x1,
  * the first aggregation pass of a direction for the other 17) behind the packed lengths, 6 / 7 = tile kernel that READS it:
  * `scratch` must be 16-byte aligned and hold mc_cbca_scratch_bytes(H, W) + mc_cbca_plan_bytes(D, H, W) bytes, and a 6 / 7 call
  * must follow a 4 / 5 call with the same arms, D, H, W, direction and scratch.
+ * 8 / 9 = the lean + list kernels mc_predict runs on textured pairs (route of the strip kernel, arms <= 13): 8 first lists the
+ * outputs whose support is not the minimal 3 x 3 behind the packed lengths (same scratch size as 4 - 7), 9 reads that list; the
+ * strip kernel takes over if the list is another problem's or did not fit.  There `rb` = rows per wave, `d0` = bits 0-1 rows in
+ * flight (6 / 3 / 9 / 12), bit 2 the listed outputs in a launch of their own, `nd` = slots the list may hold (0 = all of its room).
  * Lets small-shape parity tests reach what the benchmarked sizes and parameter sets select. */
 size_t mc_cbca_plan_bytes(int D, int H, int W);
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,

@@ -17,6 +17,7 @@ SYMBOLS = [
     "mc_interpolate_mismatch", "mc_subpixel_enchancement", "mc_median2d", "mc_mean2d", "mc_gaussian_host",
     "mc_normalize_forward", "mc_predict_workspace_bytes", "mc_predict", "mc_predict_timed",
     "mc_cbca_plan_bytes", "mc_cbca_ws_cfg", "mc_transpose_cfg",
+    "mc_read_png16", "mc_write_png16", "mc_write_pfm",
 ]
 
 
@@ -74,6 +75,9 @@ def _load():
                              C.POINTER(C.c_float)],
         "mc_cbca_ws_cfg": [vp, vp, vp, vp, i, i, i, i, vp, sz, i, i, i, i, i, vp],
         "mc_transpose_cfg": [vp, vp, i64, i64, i64, i64, f, i, vp],
+        "mc_read_png16": [C.c_char_p, vp, i64, C.POINTER(i), C.POINTER(i)],
+        "mc_write_png16": [vp, i, i, C.c_char_p],
+        "mc_write_pfm": [vp, i, i, C.c_char_p],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -81,7 +85,7 @@ def _load():
         if name not in ("mc_sgm2_tmp_bytes", "mc_cbca_scratch_bytes", "mc_cbca_plan_bytes", "mc_census_scratch_bytes",
                         "mc_fc_stack_workspace_bytes", "mc_conv3x3_workspace_bytes"):
             fn.restype = C.c_int
-    if lib.mc_version() != 6:
+    if lib.mc_version() != 7:
         raise ImportError("mc-cnn_amd: ABI version mismatch")
     return lib
 
@@ -96,4 +100,4 @@ class McError(RuntimeError):
 def check(rc, what=""):
     if rc != 0:
         msg = lib.mc_last_error()
-        raise McError("%s failed (rc=%d): %s" % (what or "libmcadcensus call", rc, msg.decode() if msg else ""))
+        raise McError("%s failed (rc=%d): %s" % (what or "libmcadcensus call", rc, msg.decode("utf-8", "replace") if msg else ""))

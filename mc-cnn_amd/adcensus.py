@@ -281,3 +281,36 @@ def gaussian(sigma):
     if rc != ks:
         check(rc, "gaussian")
     return k
+
+
+# ---- host side of libadcensus: ground-truth / submission image formats (torch.FloatTensor in the reference) -------------------
+
+def readPNG16(img, fname):
+    """adcensus.readPNG16(img, fname) -- adcensus.cu:1670-1686: fills the (H,W) float32 CPU tensor `img` with val / 256 (0 stays 0)."""
+    import ctypes as C
+    assert img.dtype == torch.float32 and img.device.type == "cpu" and img.is_contiguous(), "readPNG16: contiguous float32 CPU tensor expected"
+    h, w = C.c_int(), C.c_int()
+    check(lib.mc_read_png16(str(fname).encode(), C.c_void_p(img.data_ptr()), img.numel(), C.byref(h), C.byref(w)), "readPNG16")
+    return h.value, w.value
+
+
+def png16_size(fname):
+    """(height, width) of a PNG file (mc_read_png16's size query): what a caller sizes the tensor for readPNG16 with."""
+    import ctypes as C
+    h, w = C.c_int(), C.c_int()
+    check(lib.mc_read_png16(str(fname).encode(), None, 0, C.byref(h), C.byref(w)), "readPNG16")
+    return h.value, w.value
+
+
+def writePNG16(img, height, width, fname):
+    """adcensus.writePNG16(img, height, width, fname) -- adcensus.cu:1688-1704."""
+    import ctypes as C
+    assert img.dtype == torch.float32 and img.device.type == "cpu" and img.is_contiguous() and img.numel() >= height * width
+    check(lib.mc_write_png16(C.c_void_p(img.data_ptr()), int(height), int(width), str(fname).encode()), "writePNG16")
+
+
+def writePFM(img, fname):
+    """adcensus.writePFM(img, fname) -- adcensus.cu:1706-1721."""
+    import ctypes as C
+    assert img.dtype == torch.float32 and img.device.type == "cpu" and img.is_contiguous() and img.dim() == 2
+    check(lib.mc_write_pfm(C.c_void_p(img.data_ptr()), img.shape[0], img.shape[1], str(fname).encode()), "writePFM")

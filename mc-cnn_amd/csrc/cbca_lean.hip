@@ -407,7 +407,7 @@ int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int 
 	return check_launch("cbca_classify");
 }
 
-// one aggregation pass: the lean kernel over every output + the listed outputs (cfg.variant: bits 0-1 rows in flight 6 / 3 / 9,
+// one aggregation pass: the lean kernel over every output + the listed outputs (cfg.variant: bits 0-1 rows in flight 6 / 3 / 9 / 12,
 // bit 2 the listed outputs in a launch of their own)
 int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
               int route, hipStream_t st, const CbcaCfg &cfg)
@@ -428,6 +428,7 @@ int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const flo
 		} } while (0)
 	if (pf == 1) MC_LEAN_LAUNCH(3);
 	else if (pf == 2) MC_LEAN_LAUNCH(9);
+	else if (pf == 3) MC_LEAN_LAUNCH(12);
 	else MC_LEAN_LAUNCH(6);
 #undef MC_LEAN_LAUNCH
 	int rc = check_launch("cbca_lean");

@@ -1,0 +1,180 @@
+// Host side of libadcensus that `main.lua` reaches through the same table: adcensus.readPNG16 / writePNG16 / writePFM
+// (adcensus.cu:1670-1721; callers main.lua:1212,1218 and the KITTI / Middlebury submission paths).  Plain host code on HOST
+// pointers (the reference takes torch.FloatTensor here, not CudaTensor); no device, no stream.
+//
+// The reference goes through png++ / libpng; neither has headers in this image, zlib has: the 16-bit greyscale PNG codec
+// below is written against the PNG specification (signature, IHDR / IDAT / IEND chunks with CRC-32, zlib stream, the five
+// scanline filters) and handles exactly what these functions exchange -- 16-bit greyscale, non-interlaced (KITTI ground truth
+// and submission files); 8-bit greyscale files are accepted on read and scaled as libpng's 8 -> 16 bit expansion does (v * 257).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <zlib.h>
+
+#include "../../include/mc_adcensus.h"
+
+namespace mc {
+void set_error(const char *fmt, ...);
+}
+using mc::set_error;
+
+namespace {
+
+struct File {
+	FILE *f;
+	explicit File(const char *name, const char *mode) : f(fopen(name, mode)) {}
+	~File() { if (f) fclose(f); }
+};
+
+uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+void put_be32(unsigned char *p, uint32_t v) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; }
+
+const unsigned char PNG_SIG[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+
+int paeth(int a, int b, int c)
+{
+	const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+	return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+bool write_chunk(FILE *f, const char type[4], const unsigned char *data, size_t n)
+{
+	unsigned char hd[8];
+	put_be32(hd, (uint32_t)n);
+	memcpy(hd + 4, type, 4);
+	uLong crc = crc32(0L, (const Bytef *)type, 4);
+	if (n) crc = crc32(crc, data, (uInt)n);
+	unsigned char tail[4];
+	put_be32(tail, (uint32_t)crc);
+	return fwrite(hd, 1, 8, f) == 8 && (n == 0 || fwrite(data, 1, n, f) == n) && fwrite(tail, 1, 4, f) == 4;
+}
+
+}  // namespace
+
+extern "C" {
+
+// adcensus.readPNG16(img, fname), adcensus.cu:1670-1686: img[i * width + j] = val == 0 ? 0.0 : val / 256.0 (float).
+int mc_read_png16(const char *fname, float *img, int64_t capacity, int *height, int *width)
+{
+	if (!fname || !height || !width) { set_error("mc_read_png16: null argument"); return MC_EINVAL; }
+	File fp(fname, "rb");
+	if (!fp.f) { set_error("mc_read_png16: cannot open %s", fname); return MC_EINVAL; }
+	unsigned char sig[8];
+	if (fread(sig, 1, 8, fp.f) != 8 || memcmp(sig, PNG_SIG, 8)) { set_error("mc_read_png16: %s is not a PNG file", fname); return MC_EINVAL; }
+	uint32_t W = 0, H = 0;
+	int depth = 0;
+	bool have_hdr = false, done = false;
+	std::vector<unsigned char> z;
+	while (!done) {
+		unsigned char hd[8];
+		if (fread(hd, 1, 8, fp.f) != 8) { set_error("mc_read_png16: %s: truncated", fname); return MC_EINVAL; }
+		const uint32_t n = be32(hd);
+		if (n > (1u << 30)) { set_error("mc_read_png16: %s: bad chunk length", fname); return MC_EINVAL; }
+		std::vector<unsigned char> d(n + 4);
+		if (fread(d.data(), 1, n + 4, fp.f) != n + 4) { set_error("mc_read_png16: %s: truncated chunk", fname); return MC_EINVAL; }
+		uLong crc = crc32(0L, hd + 4, 4);
+		if (n) crc = crc32(crc, d.data(), n);
+		char type[5] = {0, 0, 0, 0, 0};   // (printable form of the chunk type for messages: a damaged file may hold anything there)
+		for (int k = 0; k < 4; ++k) type[k] = ((hd[4 + k] | 0x20) >= 'a' && (hd[4 + k] | 0x20) <= 'z') ? (char)hd[4 + k] : '?';
+		if ((uint32_t)crc != be32(d.data() + n)) { set_error("mc_read_png16: %s: CRC mismatch in chunk %s", fname, type); return MC_EINVAL; }
+		if (!memcmp(hd + 4, "IHDR", 4)) {
+			if (n != 13) { set_error("mc_read_png16: %s: bad IHDR", fname); return MC_EINVAL; }
+			W = be32(d.data()); H = be32(d.data() + 4);
+			depth = d[8];
+			const int colour = d[9], interlace = d[12];
+			if (colour != 0 || (depth != 16 && depth != 8) || interlace != 0 || d[10] != 0 || d[11] != 0) {
+				set_error("mc_read_png16: %s: only non-interlaced 8 / 16-bit greyscale PNGs are supported (colour type %d, depth %d, interlace %d)",
+				          fname, colour, depth, interlace);
+				return MC_EINVAL;
+			}
+			if (W == 0 || H == 0 || W > (1u << 20) || H > (1u << 20)) { set_error("mc_read_png16: %s: bad size", fname); return MC_EINVAL; }
+			have_hdr = true;
+		} else if (!memcmp(hd + 4, "IDAT", 4)) {
+			z.insert(z.end(), d.begin(), d.begin() + n);
+		} else if (!memcmp(hd + 4, "IEND", 4)) {
+			done = true;
+		} else if (!(hd[4] & 0x20)) {   // an unknown CRITICAL chunk (upper-case first letter)
+			set_error("mc_read_png16: %s: unsupported critical chunk %s", fname, type);
+			return MC_EINVAL;
+		}
+	}
+	if (!have_hdr || z.empty()) { set_error("mc_read_png16: %s: no image data", fname); return MC_EINVAL; }
+	*height = (int)H; *width = (int)W;
+	if (!img) return 0;   // (size query)
+	if (capacity < (int64_t)H * W) { set_error("mc_read_png16: %s is %u x %u, the buffer holds %lld pixels", fname, H, W, (long long)capacity); return MC_EINVAL; }
+	const size_t bpp = depth / 8, stride = (size_t)W * bpp;
+	std::vector<unsigned char> raw((stride + 1) * H);
+	uLongf rawlen = (uLongf)raw.size();
+	if (uncompress(raw.data(), &rawlen, z.data(), (uLong)z.size()) != Z_OK || rawlen != raw.size()) {
+		set_error("mc_read_png16: %s: bad zlib stream", fname);
+		return MC_EINVAL;
+	}
+	std::vector<unsigned char> prev(stride, 0);
+	for (uint32_t y = 0; y < H; ++y) {
+		unsigned char *row = raw.data() + (stride + 1) * y;
+		const int ft = row[0];
+		unsigned char *cur = row + 1;
+		if (ft > 4) { set_error("mc_read_png16: %s: bad filter type %d", fname, ft); return MC_EINVAL; }
+		for (size_t i = 0; i < stride; ++i) {
+			const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+			const int pred = ft == 0 ? 0 : ft == 1 ? a : ft == 2 ? b : ft == 3 ? (a + b) / 2 : paeth(a, b, c);
+			cur[i] = (unsigned char)(cur[i] + pred);
+		}
+		for (uint32_t x = 0; x < W; ++x) {
+			const uint16_t val = depth == 16 ? (uint16_t)((cur[2 * x] << 8) | cur[2 * x + 1]) : (uint16_t)(cur[x] * 257);
+			img[(size_t)y * W + x] = val == 0 ? 0.0f : ((float)val) / 256.0f;   // adcensus.cu:1682
+		}
+		memcpy(prev.data(), cur, stride);
+	}
+	return 0;
+}
+
+// adcensus.writePNG16(img, height, width, fname), adcensus.cu:1688-1704: (uint16_t)(val < 1e-5 ? 0 : val * 256) per pixel (the
+// comparison in double, the product in float, truncation), 16-bit greyscale.
+int mc_write_png16(const float *img, int height, int width, const char *fname)
+{
+	if (!img || !fname || height < 1 || width < 1) { set_error("mc_write_png16: bad argument"); return MC_EINVAL; }
+	const size_t stride = (size_t)width * 2;
+	std::vector<unsigned char> raw((stride + 1) * height);
+	for (int y = 0; y < height; ++y) {
+		unsigned char *row = raw.data() + (stride + 1) * y;
+		row[0] = 0;   // filter type None
+		for (int x = 0; x < width; ++x) {
+			const float val = img[(size_t)y * width + x];
+			const float q = (double)val < 1e-5 ? 0.0f : val * 256;
+			const uint16_t v = q == q ? (uint16_t)(long long)q : 0;   // (the reference's float -> uint16_t conversion; NaN, which it leaves undefined, becomes 0)
+			row[1 + 2 * x] = (unsigned char)(v >> 8);
+			row[2 + 2 * x] = (unsigned char)v;
+		}
+	}
+	uLongf zlen = compressBound((uLong)raw.size());
+	std::vector<unsigned char> z(zlen);
+	if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { set_error("mc_write_png16: deflate failed"); return MC_EINVAL; }
+	File fp(fname, "wb");
+	if (!fp.f) { set_error("mc_write_png16: cannot open %s", fname); return MC_EINVAL; }
+	unsigned char ihdr[13];
+	put_be32(ihdr, (uint32_t)width); put_be32(ihdr + 4, (uint32_t)height);
+	ihdr[8] = 16; ihdr[9] = 0; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+	const bool ok = fwrite(PNG_SIG, 1, 8, fp.f) == 8 && write_chunk(fp.f, "IHDR", ihdr, 13) && write_chunk(fp.f, "IDAT", z.data(), zlen) &&
+	                write_chunk(fp.f, "IEND", nullptr, 0);
+	if (!ok) { set_error("mc_write_png16: write to %s failed", fname); return MC_EINVAL; }
+	return 0;
+}
+
+// adcensus.writePFM(img, fname), adcensus.cu:1706-1721: "Pf", "width height", scale -0.003922 (negative = little-endian), the
+// rows as stored (no flip), raw floats.
+int mc_write_pfm(const float *img, int height, int width, const char *fname)
+{
+	if (!img || !fname || height < 1 || width < 1) { set_error("mc_write_pfm: bad argument"); return MC_EINVAL; }
+	File fp(fname, "wb");
+	if (!fp.f) { set_error("mc_write_pfm: cannot open %s", fname); return MC_EINVAL; }
+	if (fprintf(fp.f, "Pf\n%d %d\n-0.003922\n", width, height) < 0 || fwrite(img, 4, (size_t)height * width, fp.f) != (size_t)height * width) {
+		set_error("mc_write_pfm: write to %s failed", fname);
+		return MC_EINVAL;
+	}
+	return 0;
+}
+
+}  // extern "C"

@@ -79,10 +79,13 @@ int mc_predict(const mc_params *p, const float *x0, const float *x1,
                void *workspace, size_t workspace_bytes,
                float *volL_out, float *volR_out, float *dispL0_out, float *dispR0_out,
                float *disp_out, void *stream);
+int mc_read_png16(const char *fname, float *img, int64_t capacity, int *height, int *width);
+int mc_write_png16(const float *img, int height, int width, const char *fname);
+int mc_write_pfm(const float *img, int height, int width, const char *fname);
 ]]
 
 local lib = ffi.load('mcadcensus')
-local MC_ABI_VERSION = 6   -- include/mc_adcensus.h; tests/test_lua_shim.py checks this constant and every prototype above
+local MC_ABI_VERSION = 7   -- include/mc_adcensus.h; tests/test_lua_shim.py checks this constant and every prototype above
 assert(lib.mc_version() == MC_ABI_VERSION, ('libmcadcensus ABI version %d, this shim is written for %d'):format(
    lib.mc_version(), MC_ABI_VERSION))
 
@@ -230,6 +233,28 @@ function adcensus.Normalize_forward(input, norm, output)     -- adcensus.cu:1310
    check(lib.mc_normalize_forward(ptr(input, 'Normalize_forward'), ptr(norm, 'Normalize_forward'),
                                   ptr(output, 'Normalize_forward'), input:size(1), input:size(2), input:size(3),
                                   input:size(4), nil), 'Normalize_forward')
+end
+
+-- host side of libadcensus (torch.FloatTensor arguments, as in the reference): KITTI ground truth / submission files
+local function hostptr(t, what)
+   if torch.typename(t) ~= 'torch.FloatTensor' then
+      error(('%s: torch.FloatTensor expected, got %s'):format(what, torch.typename(t) or type(t)), 3)
+   end
+   if not t:isContiguous() then error(what .. ': contiguous tensor expected', 3) end
+   return t:data()
+end
+
+function adcensus.readPNG16(img, fname)                      -- adcensus.cu:1670-1686
+   local h, w = ffi.new('int[1]'), ffi.new('int[1]')
+   check(lib.mc_read_png16(fname, hostptr(img, 'readPNG16'), img:nElement(), h, w), 'readPNG16')
+end
+
+function adcensus.writePNG16(img, height, width, fname)      -- adcensus.cu:1688-1704
+   check(lib.mc_write_png16(hostptr(img, 'writePNG16'), height, width, fname), 'writePNG16')
+end
+
+function adcensus.writePFM(img, fname)                       -- adcensus.cu:1706-1721
+   check(lib.mc_write_pfm(hostptr(img, 'writePFM'), img:size(1), img:size(2), fname), 'writePFM')
 end
 
 -- NEW entry (no counterpart in libadcensus): the whole of stereo_predict (main.lua:929-1082) from the cost-volume stage

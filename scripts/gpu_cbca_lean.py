@@ -34,6 +34,6 @@ def run(tag, **kw):
 run("strip kernel", form=1)
 # (a pass that reads the list must use the rows per wave the list was written for: every variant lists first -- form 8 -- the kernels'
 # own times are in the rocprofv3 trace, per kernel name and grid size)
-for variant, tag in ((0, "PF=6, listed outputs inline"), (4, "PF=6, listed outputs in their own launch"), (1, "PF=3 inline"), (2, "PF=9 inline")):
-    for rb in ((0, 32, 64, 250, 500) if variant in (0, 4) else (0,)):
+for variant, tag in ((0, "PF=6 inline"), (4, "PF=6, listed outputs in their own launch"), (2, "PF=9 inline"), (3, "PF=12 inline"), (6, "PF=9 own"), (7, "PF=12 own")):
+    for rb in (0, 250, 500, 1000):
         run("classify + lean<%s> rb=%d" % (tag, rb), form=8, rb=rb, d0=variant)

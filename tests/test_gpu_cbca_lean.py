@@ -48,7 +48,7 @@ def test_lean_and_list(mc, oracle, H, W, D, mk, L1, tau1):
 
 
 @pytest.mark.parametrize("rb", [1, 2, 3, 7, 16, 64])
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 6])   # bits 0-1: rows in flight 6 / 3 / 9, bit 2: the listed outputs in a launch of their own
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6, 7])   # bits 0-1: rows in flight 6 / 3 / 9 / 12, bit 2: the listed outputs in a launch of their own
 def test_lean_rows_per_wave_and_prefetch_depth(mc, oracle, rb, variant):
     H, W, D = 61, 530, 5
     x0, x1 = smooth_pair(H, W, 8, seed=3)

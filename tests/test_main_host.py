@@ -344,3 +344,71 @@ def test_t7_reader_on_fixtures_from_an_independent_writer(name, mode):
     if mode == "ascii":
         convs, fcs = t7.load_reference_net(path, "fast")
         assert fcs is None and len(convs) == 2 and np.array_equal(convs[0][0], w1) and np.array_equal(convs[1][1], b2)
+
+
+def test_png16_and_pfm_behind_the_c_abi(tmp_path):
+    """adcensus.readPNG16 / writePNG16 / writePFM (adcensus.cu:1670-1721) as host entries of libmcadcensus.so (mc_read_png16,
+    mc_write_png16, mc_write_pfm: what the Lua shim binds), against the Python host's restatement (binio, through PIL / libpng)
+    in both directions, on filtered and unfiltered files, 8-bit files, and on the error paths"""
+    import ctypes as C
+    import torch
+    from PIL import Image
+    import mc_cnn_amd as mc
+    from mc_cnn_amd import binio
+    A = mc.adcensus
+    rng = np.random.default_rng(5)
+    H, W = 37, 53
+    d = (rng.random((H, W)) * 200).astype(np.float32)
+    d[0, :5] = [0.0, 1e-6, 9.9e-6, 1.1e-5, 255.99609375]      # below / around the 1e-5 cut, the largest 16-bit value
+    d[1, :3] = [0.00390625, 0.0039, 128.5]                    # exactly one count, just below it
+    # C writer -> libpng reader (PIL) and the C reader; identical pixels to the Python writer's file
+    pc, pp = str(tmp_path / "c.png"), str(tmp_path / "py.png")
+    A.writePNG16(torch.from_numpy(d), H, W, pc)
+    binio.write_png16(d, pp)
+    a, b = np.asarray(Image.open(pc)), np.asarray(Image.open(pp))
+    assert a.dtype == np.uint16 and a.shape == (H, W) and np.array_equal(a, b)
+    assert A.png16_size(pp) == (H, W)
+    for path in (pc, pp):     # pp was written by libpng with its own filter heuristics: the reader undoes every filter type
+        got = torch.empty((H, W), dtype=torch.float32)
+        assert A.readPNG16(got, path) == (H, W)
+        want = binio.read_png16(path)
+        assert got.numpy().tobytes() == want.tobytes()
+    # a smooth 16-bit image written by libpng with adaptive filtering (Sub / Up / Average / Paeth rows all occur)
+    ys, xs = np.mgrid[0:120, 0:200]
+    smooth = (3000 + 40 * ys + 25 * xs + (7 * np.sin(xs / 9.0) * ys)).astype(np.uint16)
+    ps = str(tmp_path / "smooth.png")
+    Image.fromarray(smooth).save(ps, format="PNG", optimize=True)
+    got = torch.empty(smooth.shape, dtype=torch.float32)
+    A.readPNG16(got, ps)
+    assert got.numpy().tobytes() == binio.read_png16(ps).tobytes()
+    # 8-bit greyscale: libpng's expansion to 16 bits (v * 257), then / 256
+    p8 = str(tmp_path / "g8.png")
+    g8 = rng.integers(0, 256, (9, 11), dtype=np.uint8)
+    Image.fromarray(g8).save(p8)
+    got = torch.empty((9, 11), dtype=torch.float32)
+    A.readPNG16(got, p8)
+    want8 = np.where(g8 == 0, np.float32(0), (g8.astype(np.uint16) * 257).astype(np.float32) / np.float32(256))
+    assert np.array_equal(got.numpy(), want8)
+    # PFM: byte-identical to the Python writer (header "Pf\n<W> <H>\n-0.003922\n", rows as stored)
+    qc, qp = str(tmp_path / "c.pfm"), str(tmp_path / "py.pfm")
+    A.writePFM(torch.from_numpy(d), qc)
+    binio.write_pfm(d, qp)
+    assert open(qc, "rb").read() == open(qp, "rb").read()
+    # errors: reported like every other entry (rc != 0 + mc_last_error), nothing written through a too small buffer
+    small = torch.full((4,), -1.0)
+    with pytest.raises(mc._lib.McError, match="buffer holds"):
+        A.readPNG16(small, pc)
+    assert (small == -1).all()
+    with pytest.raises(mc._lib.McError, match="cannot open"):
+        A.png16_size(str(tmp_path / "missing.png"))
+    open(str(tmp_path / "junk.png"), "wb").write(b"not a png at all")
+    with pytest.raises(mc._lib.McError, match="not a PNG"):
+        A.png16_size(str(tmp_path / "junk.png"))
+    rgb = str(tmp_path / "rgb.png")
+    Image.fromarray(rng.integers(0, 255, (5, 5, 3), dtype=np.uint8)).save(rgb)
+    with pytest.raises(mc._lib.McError, match="greyscale"):
+        A.png16_size(rgb)
+    bad = bytearray(open(pc, "rb").read()); bad[40] ^= 0xff
+    open(str(tmp_path / "crc.png"), "wb").write(bytes(bad))
+    with pytest.raises(mc._lib.McError, match="CRC|zlib"):
+        A.readPNG16(torch.empty((H, W)), str(tmp_path / "crc.png"))
