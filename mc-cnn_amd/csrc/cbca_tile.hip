@@ -188,6 +188,264 @@ __device__ __forceinline__ void tile_taps3_p(float (&v)[9], unsigned pa, int n, 
 
 }  // namespace
 
+// item i = (column c, row group g): outputs window rows A + 4g .. A + 4g + 3 of column c; height = rows from the topmost
+// first row to the bottommost last row of its outputs that have a partner.  Window rows 0 .. (ring rows) - 1, ring slot of
+// window row w = (base + w) mod RR.
+template <int A, int TW, int RR>
+__device__ __forceinline__ cb_u32 tile_item_rows(const unsigned char *__restrict__ UDl, int base, int c, int g, int (&s0)[4], int (&e0)[4], int &top, int &bot)
+{
+	top = 1 << 20; bot = -1;
+	int slot = base + A + 4 * g;
+	cb_u32 udall = 0;
+#pragma unroll
+	for (int j = 0; j < 4; ++j, ++slot) {
+		slot = slot >= RR ? slot - RR : slot;
+		const cb_u32 ud = UDl[slot * TW + c];
+		udall |= ud << (8 * j);
+		const bool ok = ud != 0xffu;
+		const int up = (int)(ud & 15u), dn = (int)(ud >> 4);
+		s0[j] = ok ? 4 * g + j + A - up : 1 << 20;    // window row of the output's first / last support row
+		e0[j] = ok ? 4 * g + j + A + dn : -1;
+		top = min(top, s0[j]);
+		bot = max(bot, e0[j]);
+	}
+	return udall;
+}
+
+// One work unit of a step (cbca_tile_kernel's chunk phase; window of the step = ring rows base .. base + TH + 2A - 1 mod RR):
+// units [0, usplit) are split units of 16 tall items, one OUTPUT per lane; the others are chunks of 64 items of the sorted table,
+// tallest first: the general walk, then the class of four three-row outputs (from item ngen on), then the class of four 3 x 3
+// supports (from item nfast on).  Results go to the step's tile OUTl.
+template <int A, int TW, int SW, int RR, bool PIPE>
+__device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict__ Vl, const unsigned short *__restrict__ Ml,
+                                          const unsigned char *__restrict__ UDl, float *__restrict__ OUTl, const unsigned short *__restrict__ TABl,
+                                          int base, int nz, int nfast, int ngen, int nsplit, int usplit)
+{
+	constexpr int AH = (A + 3) & ~3;
+	if (unit < usplit) {
+		const int it = unit * 16 + (lane >> 2), j = lane & 3;
+		const bool hasi = it < nsplit;
+		const cb_u32 ent = TABl[hasi ? it : 0];
+		const int c = (int)(ent & 0xffu), g = (int)((ent >> 8) & 7u);
+		const int E = __builtin_amdgcn_readfirstlane((int)(ent >> 11)) - 1;   // lane 0: the unit's tallest item, key = height + 1
+		// the item's rows (as every lane of the item walks them: one LDS address per item and row), this lane's output inside them
+		int s0[4], e0[4], top, bot;
+		tile_item_rows<A, TW, RR>(UDl, base, c, g, s0, e0, top, bot);
+		const int sj = j == 0 ? s0[0] : j == 1 ? s0[1] : j == 2 ? s0[2] : s0[3];
+		const int ej = j == 0 ? e0[0] : j == 1 ? e0[1] : j == 2 ? e0[2] : e0[3];
+		const bool outp = hasi && ej >= 0;
+		const int ext = hasi ? bot - top + 1 : 0;
+		// rows of the walk that belong to this output: bits sj - top .. ej - top
+		cb_u32 mine = outp ? ((2u << (ej - top)) - (1u << (sj - top))) : 0u;
+		asm volatile("" : "+v"(mine));
+		cb_u32 extbit = 1u << ext;
+		asm volatile("" : "+v"(extbit));
+		const cb_u32 Ebit = 1u << E;
+		int slot = hasi ? base + top : 0;
+		slot = slot >= RR ? slot - RR : slot;
+		const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;
+		float sum = 0.0f;
+		int Pn = 0;
+		__builtin_amdgcn_s_setprio(2);
+		cb_u32 mnext = ext > 0 ? (cb_u32)Ml[slot * TW + c] : 0u;
+		for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 1) {
+			const cb_u32 m = mnext;
+			const int n = (mine & ibit) ? (int)(m >> 8) : 0;
+			const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
+			slot = slot + 1 == RR ? 0 : slot + 1;
+			const cb_u32 mr = Ml[slot * TW + c];
+			mnext = (ibit << 1) < extbit ? mr : 0u;
+			tile_taps1<(A > 4)>(pa, n, sum);
+			Pn += n;
+		}
+		__builtin_amdgcn_s_setprio(0);
+		if (outp) OUTl[(4 * g + j) * TW + c] = sum / (float)Pn;
+		return;
+	}
+	const int i0 = nsplit + (unit - usplit) * 64;   // first item of the chunk
+	const int idx = i0 + lane;
+	const bool has = idx < nz;
+	const cb_u32 ent = TABl[has ? idx : 0];
+	const int c = (int)(ent & 0xffu), g = (int)((ent >> 8) & 7u);
+	if (i0 >= nfast) {
+		// every item of the chunk is four 3 x 3 supports: six rows x three values, nine additions per output in the
+		// reference's order, no lengths to look at
+		int slot = base + A + 4 * g - 1;
+		slot = slot >= RR ? slot - RR : slot;
+		float fs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+		for (int r = 0; r < 6; ++r) {   // window row r is row r - j of output j: outputs max(0, r - 2) .. min(3, r)
+			const float *__restrict__ p = Vl + slot * SW + c + AH - 1;
+			const float v0 = p[0], v1 = p[1], v2 = p[2];
+			slot = slot + 1 == RR ? 0 : slot + 1;
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+				if (j <= r && r <= j + 2) { fs[j] += v0; fs[j] += v1; fs[j] += v2; }
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+			if (has) OUTl[(4 * g + j) * TW + c] = fs[j] / 9.0f;
+		return;
+	}
+	if (i0 >= ngen) {
+		// every item of the chunk has four outputs of three rows each (the minimal class's items at its end included): window
+		// row r of the item's six is row r - j of output j, so it feeds outputs max(0, r - 2) .. min(3, r) -- no first / last
+		// rows to watch, only the runs to look up
+		int slot = base + A + 4 * g - 1;
+		slot = slot >= RR ? slot - RR : slot;
+		const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;
+		float fs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+		int nr[6];
+		if constexpr (PIPE) {   // the six run words first, then every row's values requested while the row before it is summed
+			cb_u32 pa[6];
+#pragma unroll
+			for (int r = 0; r < 6; ++r) {
+				const cb_u32 m = has ? (cb_u32)Ml[slot * TW + c] : 0u;
+				nr[r] = (int)(m >> 8);
+				pa[r] = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
+				slot = slot + 1 == RR ? 0 : slot + 1;
+			}
+			float va[9], vb[9];
+			tile_load9(va, pa[0]);
+			tile_load9(vb, pa[1]);
+			tile_taps1_p<(A > 4)>(va, pa[0], nr[0], fs[0]);
+			tile_load9(va, pa[2]);
+			tile_taps2_p<(A > 4)>(vb, pa[1], nr[1], fs[0], fs[1]);
+			tile_load9(vb, pa[3]);
+			tile_taps3_p<(A > 4)>(va, pa[2], nr[2], fs[0], fs[1], fs[2]);
+			tile_load9(va, pa[4]);
+			tile_taps3_p<(A > 4)>(vb, pa[3], nr[3], fs[1], fs[2], fs[3]);
+			tile_load9(vb, pa[5]);
+			tile_taps2_p<(A > 4)>(va, pa[4], nr[4], fs[2], fs[3]);
+			tile_taps1_p<(A > 4)>(vb, pa[5], nr[5], fs[3]);
+		} else {
+#pragma unroll
+			for (int r = 0; r < 6; ++r) {
+				const cb_u32 m = has ? (cb_u32)Ml[slot * TW + c] : 0u;
+				nr[r] = (int)(m >> 8);
+				const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
+				slot = slot + 1 == RR ? 0 : slot + 1;
+				if (r == 0) tile_taps1<(A > 4)>(pa, nr[r], fs[0]);
+				else if (r == 1) tile_taps2<(A > 4)>(pa, nr[r], fs[0], fs[1]);
+				else if (r == 2) tile_taps3<(A > 4)>(pa, nr[r], fs[0], fs[1], fs[2]);
+				else if (r == 3) tile_taps3<(A > 4)>(pa, nr[r], fs[1], fs[2], fs[3]);
+				else if (r == 4) tile_taps2<(A > 4)>(pa, nr[r], fs[2], fs[3]);
+				else tile_taps1<(A > 4)>(pa, nr[r], fs[3]);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+			if (has) OUTl[(4 * g + j) * TW + c] = fs[j] / (float)(nr[j] + nr[j + 1] + nr[j + 2]);
+		return;
+	}
+	int s0[4], e0[4], top, bot;
+	tile_item_rows<A, TW, RR>(UDl, base, c, g, s0, e0, top, bot);
+	const int ext = has ? bot - top + 1 : 0;
+	// lane 0 holds the chunk's tallest item -- except that heights 1 and 2 share a key and that the six-row classes are sorted
+	// behind every other class
+	const int E = max(max(__builtin_amdgcn_readfirstlane(ext), 2), i0 + 64 > ngen ? 6 : 0);
+#ifndef MC_TILE_NO_SETPRIO
+	if (E >= 14) __builtin_amdgcn_s_setprio(2);   // a tall chunk is the step's critical path (one wave, a chain of thousands of instructions)
+#endif
+	// first / last row of output j, counted from the item's top, as one-hot words (0: no such output): the walk below tests
+	// them against the row's bit with one compare each
+	cb_u32 sbit[4], ebit[4];
+	bool outj[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		outj[j] = has && e0[j] >= 0;
+		sbit[j] = outj[j] ? 1u << (s0[j] - top) : 0u;
+		ebit[j] = outj[j] ? 1u << (e0[j] - top) : 0u;
+	}
+	float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+	int cb[4] = {0, 0, 0, 0}, ce[4] = {1, 1, 1, 1};   // taps of the wave-row walk before the output's first row / up to its last row
+	int Pn = 0;
+	const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;   // LDS byte address of the item's column in ring slot 0
+	int slot = has ? base + top : 0;
+	slot = slot >= RR ? slot - RR : slot;
+	const cb_u32 evmask = sbit[0] | sbit[1] | sbit[2] | sbit[3] | ebit[0] | ebit[1] | ebit[2] | ebit[3];   // rows at which an output starts or ends
+	cb_u32 extbit = 1u << ext;   // (heights <= 2 A + 4 < 32)
+	asm volatile("" : "+v"(extbit));   // (opaque: stays one compare per row)
+	const cb_u32 Ebit = 1u << E;
+	if constexpr (PIPE) {
+		// the walk, two rows in flight: while row i is summed the values of row i + 1 are on their way (requested through the
+		// run word that was fetched during row i - 1) and so is the run word of row i + 2
+		int slotC = slot, slotN = slot + 1 == RR ? 0 : slot + 1;
+		cb_u32 mC = ext > 0 ? (cb_u32)Ml[slotC * TW + c] : 0u;
+		cb_u32 mN = 2u < extbit ? (cb_u32)Ml[slotN * TW + c] : 0u;   // (1 < ext)
+		float va[9], vb[9];
+		tile_load9(va, __umul24((cb_u32)slotC, (cb_u32)(SW * 4)) + cv - (mC & 0xffu));
+		auto walk_row = [&](float (&cur)[9], float (&nxt)[9], cb_u32 ibit) {
+			const cb_u32 paN = __umul24((cb_u32)slotN, (cb_u32)(SW * 4)) + cv - (mN & 0xffu);
+			tile_load9(nxt, paN);
+			const int slotNN = slotN + 1 == RR ? 0 : slotN + 1;
+			const cb_u32 mr = Ml[slotNN * TW + c];
+			const cb_u32 mNN = (ibit << 2) < extbit ? mr : 0u;   // (i + 2 < ext)
+			const int n = (int)(mC >> 8);
+			const cb_u32 pa = __umul24((cb_u32)slotC, (cb_u32)(SW * 4)) + cv - (mC & 0xffu);
+			const bool anyev = __any(evmask & ibit);
+			if (anyev) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const bool st = sbit[j] == ibit;
+					sum[j] = st ? 0.0f : sum[j];
+					cb[j] = st ? Pn : cb[j];
+				}
+			}
+			tile_taps_p<(A > 4)>(cur, pa, n, sum);
+			Pn += n;
+			if (anyev) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const bool en = ebit[j] == ibit;
+					res[j] = en ? sum[j] : res[j];
+					ce[j] = en ? Pn : ce[j];
+				}
+			}
+			slotC = slotN; mC = mN; slotN = slotNN; mN = mNN;
+		};
+		for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 2) {
+			walk_row(va, vb, ibit);
+			if ((ibit << 1) < Ebit) walk_row(vb, va, ibit << 1);
+		}
+	} else {
+		cb_u32 mnext = ext > 0 ? (cb_u32)Ml[slot * TW + c] : 0u;
+		for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 1) {   // row i of the walk, as its (wave-uniform) bit 1 << i
+			const cb_u32 m = mnext;
+			const int n = (int)(m >> 8);
+			const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
+			slot = slot + 1 == RR ? 0 : slot + 1;
+			const cb_u32 mr = Ml[slot * TW + c];   // the next row's run travels while this row is summed
+			mnext = (ibit << 1) < extbit ? mr : 0u;   // (i + 1 < ext)
+			const bool anyev = __any(evmask & ibit);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
+			if (anyev) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const bool st = sbit[j] == ibit;   // the output's first row: its chain starts from +0.0 here
+					sum[j] = st ? 0.0f : sum[j];
+					cb[j] = st ? Pn : cb[j];
+				}
+			}
+			tile_taps<(A > 4)>(pa, n, sum);
+			Pn += n;
+			if (anyev) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const bool en = ebit[j] == ibit;   // the output's last row
+					res[j] = en ? sum[j] : res[j];
+					ce[j] = en ? Pn : ce[j];
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+		if (outj[j]) OUTl[(4 * g + j) * TW + c] = res[j] / (float)(ce[j] - cb[j]);
+#ifndef MC_TILE_NO_SETPRIO
+	if (E >= 14) __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // P.gx x P.gy regions of TW columns x P.rb rows (a multiple of TH); a block takes one (region, plane).
 // The order of a step's items depends on the pair's arms and the plane only -- not on the volume -- and a pair is aggregated many
 // times over (main.lua:998-1001, 1033-1039: 2 + 16 iterations per direction on Middlebury).  MODE 1: the launch sorts and also
@@ -408,27 +666,6 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			}
 		}
 
-		// item i = (column c, row group g): outputs window rows A + 4g .. A + 4g + 3 of column c; height = rows from the topmost
-		// first row to the bottommost last row of its outputs that have a partner.  Window rows 0 .. RR - 1, ring slot of
-		// window row w = (base + w) mod RR.
-		auto item_rows = [&](int c, int g, int (&s0)[4], int (&e0)[4], int &top, int &bot) -> cb_u32 {
-			top = 1 << 20; bot = -1;
-			int slot = base + A + 4 * g;
-			cb_u32 udall = 0;
-#pragma unroll
-			for (int j = 0; j < 4; ++j, ++slot) {
-				slot = slot >= RR ? slot - RR : slot;
-				const cb_u32 ud = UDl[slot * TW + c];
-				udall |= ud << (8 * j);
-				const bool ok = ud != 0xffu;
-				const int up = (int)(ud & 15u), dn = (int)(ud >> 4);
-				s0[j] = ok ? 4 * g + j + A - up : 1 << 20;    // window row of the output's first / last support row
-				e0[j] = ok ? 4 * g + j + A + dn : -1;
-				top = min(top, s0[j]);
-				bot = max(bot, e0[j]);
-			}
-			return udall;
-		};
 		int nz, nfast, ngen, ntall;   // items [0, ngen): general walk (the first ntall of them KT_ROWS rows or taller), [ngen, nfast): three-row class, [nfast, nz): four 3 x 3 supports
 		if constexpr (MODE != 2) {
 			// ---- items sorted by height (tallest first): counting sort ------------------------------------------------
@@ -447,7 +684,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 				const int gi = wv + k * NWAVES, i = gi * 64 + lanes;
 				const int c = i % TW, g = i / TW;
 				int s0[4], e0[4], top, bot;
-				const cb_u32 udall = item_rows(c, g, s0, e0, top, bot);
+				const cb_u32 udall = tile_item_rows<A, TW, RR>(UDl, base, c, g, s0, e0, top, bot);
 				int key = bot >= top ? max(bot - top + 2, 3) : 0;
 				if (udall == 0x11111111u) {   // all four outputs reach one row up and down: 3 x 3 each if the six rows' runs are (1, 1)
 					bool mini = true;
@@ -551,228 +788,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			if (lane == 0) unit = (int)atomicAdd(&CTRl[0], 1u);
 			unit = __builtin_amdgcn_readfirstlane(unit);
 			if (unit >= nunits) break;
-			if (unit < usplit) {
-				const int it = unit * 16 + (lane >> 2), j = lane & 3;
-				const bool hasi = it < nsplit;
-				const cb_u32 ent = TABl[hasi ? it : 0];
-				const int c = (int)(ent & 0xffu), g = (int)((ent >> 8) & 7u);
-				const int E = __builtin_amdgcn_readfirstlane((int)(ent >> 11)) - 1;   // lane 0: the unit's tallest item, key = height + 1
-				// the item's rows (as every lane of the item walks them: one LDS address per item and row), this lane's output inside them
-				int s0[4], e0[4], top, bot;
-				item_rows(c, g, s0, e0, top, bot);
-				const int sj = j == 0 ? s0[0] : j == 1 ? s0[1] : j == 2 ? s0[2] : s0[3];
-				const int ej = j == 0 ? e0[0] : j == 1 ? e0[1] : j == 2 ? e0[2] : e0[3];
-				const bool outp = hasi && ej >= 0;
-				const int ext = hasi ? bot - top + 1 : 0;
-				// rows of the walk that belong to this output: bits sj - top .. ej - top
-				cb_u32 mine = outp ? ((2u << (ej - top)) - (1u << (sj - top))) : 0u;
-				asm volatile("" : "+v"(mine));
-				cb_u32 extbit = 1u << ext;
-				asm volatile("" : "+v"(extbit));
-				const cb_u32 Ebit = 1u << E;
-				int slot = hasi ? base + top : 0;
-				slot = slot >= RR ? slot - RR : slot;
-				const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;
-				float sum = 0.0f;
-				int Pn = 0;
-				__builtin_amdgcn_s_setprio(2);
-				cb_u32 mnext = ext > 0 ? (cb_u32)Ml[slot * TW + c] : 0u;
-				for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 1) {
-					const cb_u32 m = mnext;
-					const int n = (mine & ibit) ? (int)(m >> 8) : 0;
-					const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
-					slot = slot + 1 == RR ? 0 : slot + 1;
-					const cb_u32 mr = Ml[slot * TW + c];
-					mnext = (ibit << 1) < extbit ? mr : 0u;
-					tile_taps1<(A > 4)>(pa, n, sum);
-					Pn += n;
-				}
-				__builtin_amdgcn_s_setprio(0);
-				if (outp) OUTl[(4 * g + j) * TW + c] = sum / (float)Pn;
-				continue;
-			}
-			const int i0 = nsplit + (unit - usplit) * 64;   // first item of the chunk
-			const int idx = i0 + lane;
-			const bool has = idx < nz;
-			const cb_u32 ent = TABl[has ? idx : 0];
-			const int c = (int)(ent & 0xffu), g = (int)((ent >> 8) & 7u);
-			if (i0 >= nfast) {
-				// every item of the chunk is four 3 x 3 supports: six rows x three values, nine additions per output in the
-				// reference's order, no lengths to look at
-				int slot = base + A + 4 * g - 1;
-				slot = slot >= RR ? slot - RR : slot;
-				float fs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-				for (int r = 0; r < 6; ++r) {   // window row r is row r - j of output j: outputs max(0, r - 2) .. min(3, r)
-					const float *__restrict__ p = Vl + slot * SW + c + AH - 1;
-					const float v0 = p[0], v1 = p[1], v2 = p[2];
-					slot = slot + 1 == RR ? 0 : slot + 1;
-#pragma unroll
-					for (int j = 0; j < 4; ++j)
-						if (j <= r && r <= j + 2) { fs[j] += v0; fs[j] += v1; fs[j] += v2; }
-				}
-#pragma unroll
-				for (int j = 0; j < 4; ++j)
-					if (has) OUTl[(4 * g + j) * TW + c] = fs[j] / 9.0f;
-				continue;
-			}
-			if (i0 >= ngen) {
-				// every item of the chunk has four outputs of three rows each (the minimal class's items at its end included): window
-				// row r of the item's six is row r - j of output j, so it feeds outputs max(0, r - 2) .. min(3, r) -- no first / last
-				// rows to watch, only the runs to look up
-				int slot = base + A + 4 * g - 1;
-				slot = slot >= RR ? slot - RR : slot;
-				const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;
-				float fs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-				int nr[6];
-				if constexpr (PIPE) {   // the six run words first, then every row's values requested while the row before it is summed
-					cb_u32 pa[6];
-#pragma unroll
-					for (int r = 0; r < 6; ++r) {
-						const cb_u32 m = has ? (cb_u32)Ml[slot * TW + c] : 0u;
-						nr[r] = (int)(m >> 8);
-						pa[r] = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
-						slot = slot + 1 == RR ? 0 : slot + 1;
-					}
-					float va[9], vb[9];
-					tile_load9(va, pa[0]);
-					tile_load9(vb, pa[1]);
-					tile_taps1_p<(A > 4)>(va, pa[0], nr[0], fs[0]);
-					tile_load9(va, pa[2]);
-					tile_taps2_p<(A > 4)>(vb, pa[1], nr[1], fs[0], fs[1]);
-					tile_load9(vb, pa[3]);
-					tile_taps3_p<(A > 4)>(va, pa[2], nr[2], fs[0], fs[1], fs[2]);
-					tile_load9(va, pa[4]);
-					tile_taps3_p<(A > 4)>(vb, pa[3], nr[3], fs[1], fs[2], fs[3]);
-					tile_load9(vb, pa[5]);
-					tile_taps2_p<(A > 4)>(va, pa[4], nr[4], fs[2], fs[3]);
-					tile_taps1_p<(A > 4)>(vb, pa[5], nr[5], fs[3]);
-				} else {
-#pragma unroll
-					for (int r = 0; r < 6; ++r) {
-						const cb_u32 m = has ? (cb_u32)Ml[slot * TW + c] : 0u;
-						nr[r] = (int)(m >> 8);
-						const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
-						slot = slot + 1 == RR ? 0 : slot + 1;
-						if (r == 0) tile_taps1<(A > 4)>(pa, nr[r], fs[0]);
-						else if (r == 1) tile_taps2<(A > 4)>(pa, nr[r], fs[0], fs[1]);
-						else if (r == 2) tile_taps3<(A > 4)>(pa, nr[r], fs[0], fs[1], fs[2]);
-						else if (r == 3) tile_taps3<(A > 4)>(pa, nr[r], fs[1], fs[2], fs[3]);
-						else if (r == 4) tile_taps2<(A > 4)>(pa, nr[r], fs[2], fs[3]);
-						else tile_taps1<(A > 4)>(pa, nr[r], fs[3]);
-					}
-				}
-#pragma unroll
-				for (int j = 0; j < 4; ++j)
-					if (has) OUTl[(4 * g + j) * TW + c] = fs[j] / (float)(nr[j] + nr[j + 1] + nr[j + 2]);
-				continue;
-			}
-			int s0[4], e0[4], top, bot;
-			item_rows(c, g, s0, e0, top, bot);
-			const int ext = has ? bot - top + 1 : 0;
-			// lane 0 holds the chunk's tallest item -- except that heights 1 and 2 share a key and that the six-row classes are sorted
-			// behind every other class
-			const int E = max(max(__builtin_amdgcn_readfirstlane(ext), 2), i0 + 64 > ngen ? 6 : 0);
-#ifndef MC_TILE_NO_SETPRIO
-			if (E >= 14) __builtin_amdgcn_s_setprio(2);   // a tall chunk is the step's critical path (one wave, a chain of thousands of instructions)
-#endif
-			// first / last row of output j, counted from the item's top, as one-hot words (0: no such output): the walk below tests
-			// them against the row's bit with one compare each
-			cb_u32 sbit[4], ebit[4];
-			bool outj[4];
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				outj[j] = has && e0[j] >= 0;
-				sbit[j] = outj[j] ? 1u << (s0[j] - top) : 0u;
-				ebit[j] = outj[j] ? 1u << (e0[j] - top) : 0u;
-			}
-			float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-			int cb[4] = {0, 0, 0, 0}, ce[4] = {1, 1, 1, 1};   // taps of the wave-row walk before the output's first row / up to its last row
-			int Pn = 0;
-			const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;   // LDS byte address of the item's column in ring slot 0
-			int slot = has ? base + top : 0;
-			slot = slot >= RR ? slot - RR : slot;
-			const cb_u32 evmask = sbit[0] | sbit[1] | sbit[2] | sbit[3] | ebit[0] | ebit[1] | ebit[2] | ebit[3];   // rows at which an output starts or ends
-			cb_u32 extbit = 1u << ext;   // (heights <= 2 A + 4 < 32)
-			asm volatile("" : "+v"(extbit));   // (opaque: stays one compare per row)
-			const cb_u32 Ebit = 1u << E;
-			if constexpr (PIPE) {
-				// the walk, two rows in flight: while row i is summed the values of row i + 1 are on their way (requested through the
-				// run word that was fetched during row i - 1) and so is the run word of row i + 2
-				int slotC = slot, slotN = slot + 1 == RR ? 0 : slot + 1;
-				cb_u32 mC = ext > 0 ? (cb_u32)Ml[slotC * TW + c] : 0u;
-				cb_u32 mN = 2u < extbit ? (cb_u32)Ml[slotN * TW + c] : 0u;   // (1 < ext)
-				float va[9], vb[9];
-				tile_load9(va, __umul24((cb_u32)slotC, (cb_u32)(SW * 4)) + cv - (mC & 0xffu));
-				auto walk_row = [&](float (&cur)[9], float (&nxt)[9], cb_u32 ibit) {
-					const cb_u32 paN = __umul24((cb_u32)slotN, (cb_u32)(SW * 4)) + cv - (mN & 0xffu);
-					tile_load9(nxt, paN);
-					const int slotNN = slotN + 1 == RR ? 0 : slotN + 1;
-					const cb_u32 mr = Ml[slotNN * TW + c];
-					const cb_u32 mNN = (ibit << 2) < extbit ? mr : 0u;   // (i + 2 < ext)
-					const int n = (int)(mC >> 8);
-					const cb_u32 pa = __umul24((cb_u32)slotC, (cb_u32)(SW * 4)) + cv - (mC & 0xffu);
-					const bool anyev = __any(evmask & ibit);
-					if (anyev) {
-#pragma unroll
-						for (int j = 0; j < 4; ++j) {
-							const bool st = sbit[j] == ibit;
-							sum[j] = st ? 0.0f : sum[j];
-							cb[j] = st ? Pn : cb[j];
-						}
-					}
-					tile_taps_p<(A > 4)>(cur, pa, n, sum);
-					Pn += n;
-					if (anyev) {
-#pragma unroll
-						for (int j = 0; j < 4; ++j) {
-							const bool en = ebit[j] == ibit;
-							res[j] = en ? sum[j] : res[j];
-							ce[j] = en ? Pn : ce[j];
-						}
-					}
-					slotC = slotN; mC = mN; slotN = slotNN; mN = mNN;
-				};
-				for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 2) {
-					walk_row(va, vb, ibit);
-					if ((ibit << 1) < Ebit) walk_row(vb, va, ibit << 1);
-				}
-			} else {
-				cb_u32 mnext = ext > 0 ? (cb_u32)Ml[slot * TW + c] : 0u;
-				for (cb_u32 ibit = 1u; ibit < Ebit; ibit <<= 1) {   // row i of the walk, as its (wave-uniform) bit 1 << i
-					const cb_u32 m = mnext;
-					const int n = (int)(m >> 8);
-					const cb_u32 pa = __umul24((cb_u32)slot, (cb_u32)(SW * 4)) + cv - (m & 0xffu);
-					slot = slot + 1 == RR ? 0 : slot + 1;
-					const cb_u32 mr = Ml[slot * TW + c];   // the next row's run travels while this row is summed
-					mnext = (ibit << 1) < extbit ? mr : 0u;   // (i + 1 < ext)
-					const bool anyev = __any(evmask & ibit);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
-					if (anyev) {
-#pragma unroll
-						for (int j = 0; j < 4; ++j) {
-							const bool st = sbit[j] == ibit;   // the output's first row: its chain starts from +0.0 here
-							sum[j] = st ? 0.0f : sum[j];
-							cb[j] = st ? Pn : cb[j];
-						}
-					}
-					tile_taps<(A > 4)>(pa, n, sum);
-					Pn += n;
-					if (anyev) {
-#pragma unroll
-						for (int j = 0; j < 4; ++j) {
-							const bool en = ebit[j] == ibit;   // the output's last row
-							res[j] = en ? sum[j] : res[j];
-							ce[j] = en ? Pn : ce[j];
-						}
-					}
-				}
-			}
-#pragma unroll
-			for (int j = 0; j < 4; ++j)
-				if (outj[j]) OUTl[(4 * g + j) * TW + c] = res[j] / (float)(ce[j] - cb[j]);
-#ifndef MC_TILE_NO_SETPRIO
-			if (E >= 14) __builtin_amdgcn_s_setprio(0);
-#endif
+			tile_unit<A, TW, SW, RR, PIPE>(unit, lane, Vl, Ml, UDl, OUTl, TABl, base, nz, nfast, ngen, nsplit, usplit);
 		}
 		TPROF(6);
 		__syncthreads();
@@ -823,6 +839,278 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	}
 }
 
+// =====================================================================================================
+// The plan-reading pass without a barrier per step ("rolling" form)
+// =====================================================================================================
+// What bounds cbca_tile_kernel<.., 2> on real-scene arms is the barrier behind a step's chunk phase: a step has 8 chunks for 8 waves,
+// the tallest one is a chain of thousands of instructions and the others wait for it (waves spend 55 % of their cycles waiting,
+// profiles/r03_cbca_tile_pmc_mb_natural.csv; scripts/model/tile_roll.py: 0.38 of the waves' time is work) -- and every wave then
+// executes the step's fixed part (commit, stores, requests: a fifth of all instructions).  Here the ring holds the windows of TWO
+// consecutive steps (2 TH + 2 A rows) and the block has one more wave, the MOVER, which owns everything that is not a chunk:
+//   compute waves   take work units -- global ticket numbers, in step order, tallest first inside a step -- as long as the unit's step
+//                   is READY, process them (tile_unit: the same walk as above) and count them DONE;
+//   mover           when step s is done: sends its result tile to memory, overwrites the step's oldest TH ring rows with the rows
+//                   step s + 2 adds (requested a step earlier into its registers, with the plan's runs / vertical arms / item table)
+//                   and publishes step s + 2 as ready.
+// So the compute waves run up to one step ahead of the slowest chunk instead of waiting for it (model: 0.73 of their time is work),
+// and the per-step fixed part is executed once, by a wave that has nothing else to do.  All hand-offs are LDS words (ticket, ready,
+// done[4], cumulative unit counts[4]): LDS operations of a CU are served in issue order, so "data, wait, flag" on one side and "flag,
+// data" on the other is all the ordering there is; spins are bounded (a wave that gives up raises the abort word and every wave leaves).
+template <int A, int TW, int TH, int NCW, bool NT>
+__global__ void __launch_bounds__(64 * (NCW + 1), (2 * (NCW + 1) + 3) / 4) cbca_roll_kernel(const CbcaArgs P)
+{
+	using G = TileGeo<A, TW, TH, 2>;
+	constexpr int AH = G::AH, SW = G::SW, NI = G::NI;
+	constexpr int RR = 2 * TH + 2 * A;              // ring rows: the windows of two consecutive steps
+	constexpr int NTHREADS = 64 * (NCW + 1);
+	constexpr int VOL_AUX = NT ? 2 : 0;
+	constexpr int NSPLIT_MAX = MC_TILE_NSPLIT;
+	constexpr bool PIPE = true;
+	constexpr int V_BYTES = RR * SW * 4, M_BYTES = (RR * TW * 2 + 15) & ~15, UD_BYTES = (RR * TW + 15) & ~15;
+	constexpr int OUT1 = TH * TW, TAB1 = G::TAB_BYTES / 2;   // words of one result tile / u16 of one item table
+	static_assert(G::TAB_BYTES % 16 == 0 && TW % 64 == 0 && TH % 4 == 0 && TW * 2 % 16 == 0, "roll geometry");
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	float *__restrict__ Vl = (float *)smem;
+	unsigned short *__restrict__ Ml = (unsigned short *)(smem + V_BYTES);
+	unsigned char *__restrict__ UDl = smem + V_BYTES + M_BYTES;
+	float *__restrict__ OUTl = (float *)(smem + V_BYTES + M_BYTES + UD_BYTES);                                  // two tiles: step s uses s & 1
+	unsigned short *__restrict__ TABl = (unsigned short *)(smem + V_BYTES + M_BYTES + UD_BYTES + 2 * OUT1 * 4);   // two tables
+	cb_u32 *__restrict__ CT = (cb_u32 *)(smem + V_BYTES + M_BYTES + UD_BYTES + 2 * OUT1 * 4 + 2 * G::TAB_BYTES);
+	enum { C_TICKET = 0, C_READY = 1, C_ABORT = 2, C_DONE = 4, C_NUN = 8, C_CUM = 16, C_WORDS = 24 };   // done / units per step: 4 slots, cumulative units: 8
+
+	if (!cbca_gate(P.flags, P.route)) return;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int H = P.H, W = P.W;
+	const int HWi = H * W;
+	const int xcd = blockIdx.x & 7, sblk = blockIdx.x >> 3;
+	const int region = (sblk / P.nd) * 8 + xcd;
+	const int d = P.d0 + sblk % P.nd;
+	if (region >= P.gx * P.gy) return;
+	const int cx = region % P.gx, cy = region / P.gx;
+	const int tx0 = cx * TW, ys = cy * P.rb, ye = min(H, ys + P.rb);
+	const int sh = d * P.direction;
+	const int sx0 = tx0 - AH, yr0 = ys - A;
+	const cb_u32 OOB = 0x80000000u;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(P.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
+	const int lo = max(0, -sh);
+	const cb_u32 span = (cb_u32)max(0, min(W, W - sh) - lo);
+	const bool edge_tile = tx0 < lo || tx0 + TW > lo + (int)span;
+	constexpr int ENT = G::ENT_BYTES;
+	const int nsteps = (ye - ys + TH - 1) / TH;
+	const __amdgpu_buffer_rsrc_t rplan = __builtin_amdgcn_make_buffer_rsrc(
+		(void *)((char *)P.plan + ((size_t)d * (size_t)(P.gx * P.gy) + (size_t)region) * (size_t)P.spr * ENT), 0, P.spr * ENT, 0x00020000);
+	const int Wp = P.wp;
+	const __amdgpu_buffer_rsrc_t rpm = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)P.plan + P.plan_m + (size_t)d * H * Wp * 2), 0, H * Wp * 2, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rpu = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)P.plan + P.plan_ud + (size_t)d * H * Wp), 0, H * Wp, 0x00020000);
+	const int ylast = min(H, ye + A);
+
+	// ---- one step's rows: values (16-byte units of 4 columns, all staged columns), runs (units of 8 pixels) and vertical arms (units of 16
+	// pixels) of the output columns, the step's item table (65 units).  NT threads share the work; rows outside the image: zeros / "no output".
+	constexpr int UPR = SW / 4, MPR = TW / 8, UPRD = TW / 16, TABU = G::TAB_BYTES / 16;
+	auto v_off = [&](int rr, int u) -> cb_u32 {   // relative row rr (image row yr0 + rr), value unit u
+		const int y = yr0 + rr;
+		return (y >= 0 && y < ylast) ? (cb_u32)(y * W + sx0 + 4 * u) * 4u : OOB;   // (as in cbca_tile_kernel: one 16-byte load wherever the unit starts)
+	};
+	auto commit_v = [&](const cb_u4 &v, int rr, int u) {
+		const int slot = rr % RR;
+		*(cb_u4 *)(Vl + slot * SW + 4 * u) = v;
+	};
+	auto commit_m = [&](cb_u4 m, int rr, int u) {
+		const int y = yr0 + rr;
+		if (!(y >= 0 && y < ylast)) m = cb_u4{0u, 0u, 0u, 0u};
+		*(cb_u4 *)(Ml + (rr % RR) * TW + 8 * u) = m;
+	};
+	auto commit_ud = [&](cb_u4 ud, int rr, int u) {
+		const int y = yr0 + rr;
+		if (!(y >= 0 && y < ylast)) ud = cb_u4{~0u, ~0u, ~0u, ~0u};
+		*(cb_u4 *)(UDl + (rr % RR) * TW + 16 * u) = ud;
+	};
+	auto m_off = [&](int rr, int u) -> cb_u32 {
+		const int y = yr0 + rr;
+		return (y >= 0 && y < ylast) ? (cb_u32)(y * Wp + tx0 + 8 * u) * 2u : OOB;
+	};
+	auto ud_off = [&](int rr, int u) -> cb_u32 {
+		const int y = yr0 + rr;
+		return (y >= 0 && y < ylast) ? (cb_u32)(y * Wp + tx0 + 16 * u) : OOB;
+	};
+	// outputs without a partner are copied through (adcensus.cu:353-354): whole columns of tiles that reach beyond [lo, lo + span)
+	auto copy_through = [&](int s, int t0, int nt) {
+		if (!edge_tile) return;
+		for (int q = t0; q < TH * TW; q += nt) {
+			const int r = q / TW, cc = q - r * TW;
+			if ((cb_u32)(tx0 + cc - lo) >= span) OUTl[(s & 1) * OUT1 + q] = Vl[((s * TH + A + r) % RR) * SW + AH + cc];
+		}
+	};
+	auto units_of = [&](cb_u32 nz, cb_u32 ntall) -> int {   // work units of a step (as cbca_tile_kernel)
+		const int z = min((int)nz, NI), t = min((int)ntall, z);
+		const int nsplit = (A > 4 && t <= NSPLIT_MAX) ? t : 0;
+		return ((nsplit + 15) >> 4) + ((z - nsplit + 63) >> 6);
+	};
+
+	// ---- prologue, all waves: the windows of steps 0 and 1 (relative rows 0 .. RR - 1), their tables
+	for (int q = tid; q < RR * UPR; q += NTHREADS) {
+		const int rr = q / UPR, u = q - rr * UPR;
+		commit_v(__builtin_amdgcn_raw_buffer_load_b128(rv, v_off(rr, u), 0, VOL_AUX), rr, u);
+	}
+	for (int q = tid; q < RR * MPR; q += NTHREADS) {
+		const int rr = q / MPR, u = q - rr * MPR;
+		commit_m(__builtin_amdgcn_raw_buffer_load_b128(rpm, m_off(rr, u), 0, 0), rr, u);
+	}
+	for (int q = tid; q < RR * UPRD; q += NTHREADS) {
+		const int rr = q / UPRD, u = q - rr * UPRD;
+		commit_ud(__builtin_amdgcn_raw_buffer_load_b128(rpu, ud_off(rr, u), 0, 0), rr, u);
+	}
+	for (int q = tid; q < 2 * TABU; q += NTHREADS) {
+		const int s = q / TABU, u = q - s * TABU;
+		*(cb_u4 *)(TABl + s * TAB1 + 8 * u) = __builtin_amdgcn_raw_buffer_load_b128(rplan, s < nsteps ? (cb_u32)(s * ENT + u * 16) : OOB, 0, 0);
+	}
+	if (tid < C_WORDS) CT[tid] = 0;
+	__syncthreads();
+	copy_through(0, tid, NTHREADS);
+	if (nsteps > 1) copy_through(1, tid, NTHREADS);
+	if (tid == 0) {
+		const cb_u32 *h0 = (const cb_u32 *)(TABl + NI), *h1 = (const cb_u32 *)(TABl + TAB1 + NI);
+		const int n0 = units_of(h0[0], h0[3]), n1 = nsteps > 1 ? units_of(h1[0], h1[3]) : 0;
+		CT[C_NUN + 0] = (cb_u32)n0; CT[C_NUN + 1] = (cb_u32)n1;
+		CT[C_CUM + 0] = (cb_u32)n0; CT[C_CUM + 1] = (cb_u32)(n0 + n1);
+		CT[C_READY] = (cb_u32)min(1, nsteps - 1);
+	}
+	__syncthreads();
+
+	auto lds_word = [&](int i) -> cb_u32 { return __hip_atomic_load(CT + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+	constexpr int SPIN_LIMIT = 1 << 22;   // (x 64-clock sleeps: ~0.1 s -- far beyond any step; a wave that gets here gives up for the block)
+	// spins until word i >= need (true) or the block is aborting (false)
+	auto wait_ge = [&](int i, cb_u32 need) -> bool {
+		for (int spins = 0;; ++spins) {
+			if (lds_word(i) >= need) break;
+			if (lds_word(C_ABORT)) return false;
+			if (spins > SPIN_LIMIT) { __hip_atomic_store(CT + C_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return false; }
+			__builtin_amdgcn_s_sleep(1);
+		}
+		asm volatile("" ::: "memory");
+		return true;
+	};
+
+	if (wvs < NCW) {
+		// ================= compute waves =================
+		int cs = 0, base = 0;     // the step this wave is at, ring slot of its first window row
+		cb_u32 cum0 = 0;          // units of the steps before cs
+		for (;;) {
+			cb_u32 g = 0;
+			if (lane == 0) g = atomicAdd(CT + C_TICKET, 1u);
+			g = (cb_u32)__builtin_amdgcn_readfirstlane((int)g);
+			bool alive = true;
+			for (;;) {   // the ticket's step
+				if (cs >= nsteps) { alive = false; break; }
+				if (!wait_ge(C_READY, (cb_u32)cs)) { alive = false; break; }
+				const cb_u32 ce = lds_word(C_CUM + (cs & 7));
+				if (g < ce) break;
+				cum0 = ce; ++cs;
+				base += TH; base = base >= RR ? base - RR : base;
+			}
+			if (!alive) break;
+			const int unit = (int)(g - cum0);
+			const cb_u32 *hdr = (const cb_u32 *)(TABl + (cs & 1) * TAB1 + NI);
+			const int nz = min(__builtin_amdgcn_readfirstlane((int)hdr[0]), NI);
+			const int nfast = __builtin_amdgcn_readfirstlane((int)hdr[1]);
+			const int ngen = __builtin_amdgcn_readfirstlane((int)hdr[2]);
+			const int ntall = min(__builtin_amdgcn_readfirstlane((int)hdr[3]), nz);
+			const int nsplit = (A > 4 && ntall <= NSPLIT_MAX) ? ntall : 0;
+			const int usplit = (nsplit + 15) >> 4;
+			tile_unit<A, TW, SW, RR, PIPE>(unit, lane, Vl, Ml, UDl, OUTl + (cs & 1) * OUT1, TABl + (cs & 1) * TAB1, base, nz, nfast, ngen, nsplit, usplit);
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the unit's results are in the tile
+			if (lane == 0) atomicAdd(CT + C_DONE + (cs & 3), 1u);
+		}
+		return;
+	}
+
+	// ================= mover =================
+	constexpr int NV = (TH * UPR + 63) / 64, NM = (TH * MPR + 63) / 64, NU = (TH * UPRD + 63) / 64, NT_ = (TABU + 63) / 64;
+	struct Rows { cb_u4 v[NV], m[NM], ud[NU], tab[NT_]; } R;
+	// requests the rows step s adds to the ring (relative rows s TH + 2A .. + TH - 1; s >= 2) and its table
+	auto fetch_step = [&](int s) {
+		const bool on = s < nsteps;
+		const int rr0 = s * TH + 2 * A;
+#pragma unroll
+		for (int k = 0; k < NV; ++k) {
+			const int q = lane + 64 * k, r = q / UPR, u = q - r * UPR;
+			R.v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, (on && r < TH) ? v_off(rr0 + r, u) : OOB, 0, VOL_AUX);
+		}
+#pragma unroll
+		for (int k = 0; k < NM; ++k) {
+			const int q = lane + 64 * k, r = q / MPR, u = q - r * MPR;
+			R.m[k] = __builtin_amdgcn_raw_buffer_load_b128(rpm, (on && r < TH) ? m_off(rr0 + r, u) : OOB, 0, 0);
+		}
+#pragma unroll
+		for (int k = 0; k < NU; ++k) {
+			const int q = lane + 64 * k, r = q / UPRD, u = q - r * UPRD;
+			R.ud[k] = __builtin_amdgcn_raw_buffer_load_b128(rpu, (on && r < TH) ? ud_off(rr0 + r, u) : OOB, 0, 0);
+		}
+#pragma unroll
+		for (int k = 0; k < NT_; ++k) {
+			const int q = lane + 64 * k;
+			R.tab[k] = __builtin_amdgcn_raw_buffer_load_b128(rplan, (on && q < TABU) ? (cb_u32)(s * ENT + q * 16) : OOB, 0, 0);
+		}
+	};
+	auto commit_step = [&](int s) {
+		const int rr0 = s * TH + 2 * A;
+#pragma unroll
+		for (int k = 0; k < NV; ++k) {
+			const int q = lane + 64 * k, r = q / UPR, u = q - r * UPR;
+			if (r < TH) commit_v(R.v[k], rr0 + r, u);
+		}
+#pragma unroll
+		for (int k = 0; k < NM; ++k) {
+			const int q = lane + 64 * k, r = q / MPR, u = q - r * MPR;
+			if (r < TH) commit_m(R.m[k], rr0 + r, u);
+		}
+#pragma unroll
+		for (int k = 0; k < NU; ++k) {
+			const int q = lane + 64 * k, r = q / UPRD, u = q - r * UPRD;
+			if (r < TH) commit_ud(R.ud[k], rr0 + r, u);
+		}
+#pragma unroll
+		for (int k = 0; k < NT_; ++k) {
+			const int q = lane + 64 * k;
+			if (q < TABU) *(cb_u4 *)(TABl + (s & 1) * TAB1 + 8 * q) = R.tab[k];
+		}
+	};
+	fetch_step(2);
+	cb_u32 cum = lds_word(C_CUM + 1);
+	for (int s = 0; s < nsteps; ++s) {
+		if (!wait_ge(C_DONE + (s & 3), lds_word(C_NUN + (s & 3)))) return;
+		// step s is complete: its tile leaves as rows (a row per instruction: the descriptor ends with the row, so that the words
+		// of a last unit beyond the image are dropped by the range check; rows beyond the region get an empty descriptor)
+		constexpr int OPR = TW / 4;
+		static_assert(OPR <= 64, "a row is one store instruction");
+#pragma unroll 4
+		for (int r = 0; r < TH; ++r) {
+			const int y = ys + s * TH + r;
+			const cb_f4 ov = *(const cb_f4 *)(OUTl + (s & 1) * OUT1 + r * TW + 4 * (lane < OPR ? lane : 0));
+			const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(P.vout + (size_t)d * HWi), 0, y < ye ? (y + 1) * W * 4 : 0, 0x00020000);
+			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(ov.x), __float_as_uint(ov.y), __float_as_uint(ov.z), __float_as_uint(ov.w)}, rrow,
+			                                       lane < OPR ? (cb_u32)(y * W + tx0 + 4 * lane) * 4u : OOB, 0, VOL_AUX);
+		}
+		if (lane == 0) __hip_atomic_store(CT + C_DONE + (s & 3), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (s + 2 < nsteps) {
+			commit_step(s + 2);   // (waits for the rows requested a step ago) over step s's oldest TH rows and its table
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			copy_through(s + 2, lane, 64);
+			const cb_u32 *h = (const cb_u32 *)(TABl + (s & 1) * TAB1 + NI);
+			const int nun = units_of(h[0], h[3]);
+			cum += (cb_u32)nun;
+			if (lane == 0) {
+				CT[C_NUN + ((s + 2) & 3)] = (cb_u32)nun;
+				CT[C_CUM + ((s + 2) & 7)] = cum;
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // rows, table, tile columns and counts before the step is announced
+			if (lane == 0) __hip_atomic_store(CT + C_READY, (cb_u32)(s + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		fetch_step(s + 3);
+	}
+}
+
 #ifdef MC_TILE_PROF
 extern "C" __attribute__((visibility("default"))) int mc_debug_tile_prof(unsigned long long *out, int n)
 {
@@ -843,6 +1131,12 @@ static void tile_regions(int H, int W, int TW, int TH, int &gx, int &gy, int &rb
 	gy = (int)cdiv(H, rb);
 }
 
+#ifndef MC_ROLL_DEFAULT_13
+#define MC_ROLL_DEFAULT_13 false   // (until measured)
+#endif
+#ifndef MC_ROLL_DEFAULT_4
+#define MC_ROLL_DEFAULT_4 false
+#endif
 // the product's geometries (128 x 16 tiles for either arm class) share one plan layout
 constexpr int PLAN_TW = 128, PLAN_TH = 16;
 // [item tables: D x regions x steps per region entries | combined runs (D, H, Wp) u16 | vertical arms (D, H, Wp) u8], Wp = W rounded up to whole tiles
@@ -871,19 +1165,46 @@ static int cbca_tiles_launch_mode(CbcaArgs P, bool nt, hipStream_t st)
 	}
 	auto kern_nt = cbca_tile_kernel<A, TW, TH, NWAVES, true, MODE>;
 	auto kern = cbca_tile_kernel<A, TW, TH, NWAVES, false, MODE>;
-	static bool attr_done = false;   // (idempotent; a race sets the same value twice)
-	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void *)kern_nt, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-		(void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-		attr_done = true;
+	if (G::LDS_BYTES > 64 * 1024) {   // (per device, cheap: on every launch that needs it, checked -- as mean2d does)
+		const hipError_t e = hipFuncSetAttribute(nt ? (const void *)kern_nt : (const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+		if (e != hipSuccess) {
+			set_error("cbca_tile: hipFuncSetAttribute(%d bytes of LDS): %s", G::LDS_BYTES, hipGetErrorString(e));
+			return (int)e;
+		}
 	}
 	if (nt) hipLaunchKernelGGL(kern_nt, dim3((unsigned)blocks), dim3(64 * NWAVES), G::LDS_BYTES, st, P);
 	else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWAVES), G::LDS_BYTES, st, P);
 	return check_launch("cbca_tile");
 }
 
+// the plan-reading pass in its rolling form (cbca_roll_kernel): 8 compute waves + the mover, two blocks per CU
+template <int A, int TW, int TH>
+static int cbca_roll_launch(const CbcaArgs &P, bool nt, hipStream_t st)
+{
+	using G = TileGeo<A, TW, TH, 2>;
+	constexpr int NCW = 8, RR = 2 * TH + 2 * A;
+	constexpr int LDS = RR * G::SW * 4 + ((RR * TW * 2 + 15) & ~15) + ((RR * TW + 15) & ~15) + 2 * TH * TW * 4 + 2 * G::TAB_BYTES + 24 * 4;
+	static_assert(LDS <= 80 * 1024, "two blocks per CU");
+	const int64_t blocks = (int64_t)cdiv((int64_t)P.gx * P.gy, 8) * 8 * P.nd;
+	if (blocks > 0x7fffffff) {
+		set_error("cbca_roll: %lld blocks", (long long)blocks);
+		return MC_EINVAL;
+	}
+	auto kern_nt = cbca_roll_kernel<A, TW, TH, NCW, true>;
+	auto kern = cbca_roll_kernel<A, TW, TH, NCW, false>;
+	// (more than 64 KB of dynamic LDS: the attribute is per device and cheap to set -- on every launch, checked, as mean2d does)
+	const hipError_t e = hipFuncSetAttribute(nt ? (const void *)kern_nt : (const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+	if (e != hipSuccess) {
+		set_error("cbca_roll: hipFuncSetAttribute(%d bytes of LDS): %s", LDS, hipGetErrorString(e));
+		return (int)e;
+	}
+	if (nt) hipLaunchKernelGGL(kern_nt, dim3((unsigned)blocks), dim3(64 * (NCW + 1)), LDS, st, P);
+	else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * (NCW + 1)), LDS, st, P);
+	return check_launch("cbca_roll");
+}
+
 template <int A, int TW, int TH, int NWAVES>
-static int cbca_tiles_launch(CbcaArgs P, bool nt, int plan_mode, hipStream_t st)
+static int cbca_tiles_launch(CbcaArgs P, bool nt, int plan_mode, bool roll, hipStream_t st)
 {
 	tile_regions(P.H, P.W, TW, TH, P.gx, P.gy, P.rb);
 	P.spr = P.rb / TH;
@@ -892,6 +1213,7 @@ static int cbca_tiles_launch(CbcaArgs P, bool nt, int plan_mode, hipStream_t st)
 	if constexpr (TW == PLAN_TW && TH == PLAN_TH) {
 		static_assert(TileGeo<A, TW, TH>::ENT_BYTES == TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES, "one plan layout");
 		if (plan_mode == 1) return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 1>(P, nt, st);
+		if (plan_mode == 2 && roll) return cbca_roll_launch<A, TW, TH>(P, nt, st);
 		if (plan_mode == 2) return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 2>(P, nt, st);
 	}
 	return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 0>(P, nt, st);   // (other geometries: no plan)
@@ -916,19 +1238,21 @@ int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, 
 	P.plan = pm ? cfg.plan : nullptr;
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
 	// cfg.variant selects the tile geometry (test / tuning hook; 0 = the product's choice)
+	// cfg.roll: the plan-reading pass in its rolling form (-1 = the product's choice per arm class, 0 / 1 forced)
+	const bool roll13 = cfg.roll < 0 ? MC_ROLL_DEFAULT_13 : cfg.roll != 0, roll4 = cfg.roll < 0 ? MC_ROLL_DEFAULT_4 : cfg.roll != 0;
 	if (arm_class <= 4) {
 		switch (cfg.variant) {
-		case 1: return cbca_tiles_launch<4, 128, 32, 8>(P, nt, pm, st);
-		case 2: return cbca_tiles_launch<4, 128, 32, 4>(P, nt, pm, st);
-		case 3: return cbca_tiles_launch<4, 256, 16, 8>(P, nt, pm, st);
-		default: return cbca_tiles_launch<4, 128, 16, 4>(P, nt, pm, st);
+		case 1: return cbca_tiles_launch<4, 128, 32, 8>(P, nt, pm, false, st);
+		case 2: return cbca_tiles_launch<4, 128, 32, 4>(P, nt, pm, false, st);
+		case 3: return cbca_tiles_launch<4, 256, 16, 8>(P, nt, pm, false, st);
+		default: return cbca_tiles_launch<4, 128, 16, 4>(P, nt, pm, roll4, st);
 		}
 	}
 	switch (cfg.variant) {
-	case 1: return cbca_tiles_launch<13, 128, 32, 8>(P, nt, pm, st);
-	case 2: return cbca_tiles_launch<13, 128, 16, 4>(P, nt, pm, st);
-	case 3: return cbca_tiles_launch<13, 64, 16, 4>(P, nt, pm, st);
-	default: return cbca_tiles_launch<13, 128, 16, 8>(P, nt, pm, st);
+	case 1: return cbca_tiles_launch<13, 128, 32, 8>(P, nt, pm, false, st);
+	case 2: return cbca_tiles_launch<13, 128, 16, 4>(P, nt, pm, false, st);
+	case 3: return cbca_tiles_launch<13, 64, 16, 4>(P, nt, pm, false, st);
+	default: return cbca_tiles_launch<13, 128, 16, 8>(P, nt, pm, roll13, st);
 	}
 }
 

@@ -129,13 +129,15 @@ def test_tile_kernel_with_plan(mc, oracle, H, W, D, mk, L1, tau1, forms):
         got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, vol, direction)
         assert same_bits(got, want), diff_report(got, want, "tile kernel writing the plan, dir=%d" % direction)
         for v in (vol2, vol):
-            out = torch.full((1, D, H, W), -7.0, device="cuda")
-            mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(v), out, direction, nt=(H + W) & 1, form=forms[1])
-            got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, v, direction)
-            assert same_bits(got, want), diff_report(got, want, "tile kernel reading the plan, dir=%d" % direction)
+            for rb, what in ((2, "barrier form"), (1, "rolling form")):   # the plan-reading pass: a barrier per step / compute waves + mover
+                out = torch.full((1, D, H, W), -7.0, device="cuda")
+                mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(v), out, direction, nt=(H + W) & 1, rb=rb, form=forms[1])
+                got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, v, direction)
+                assert same_bits(got, want), diff_report(got, want, "tile kernel reading the plan (%s), dir=%d" % (what, direction))
         if D >= 6:
-            out = torch.full((1, D, H, W), -7.0, device="cuda")
-            mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol2), out, direction, d0=2, nd=3, form=forms[1])
-            got = out.cpu().numpy()[0]
-            want = oracle.cbca(x0c, x1c, vol2, direction)
-            assert same_bits(got[2:5], want[2:5]) and (got[:2] == -7.0).all() and (got[5:] == -7.0).all()
+            for rb in (2, 1):
+                out = torch.full((1, D, H, W), -7.0, device="cuda")
+                mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol2), out, direction, d0=2, nd=3, rb=rb, form=forms[1])
+                got = out.cpu().numpy()[0]
+                want = oracle.cbca(x0c, x1c, vol2, direction)
+                assert same_bits(got[2:5], want[2:5]) and (got[:2] == -7.0).all() and (got[5:] == -7.0).all()
