@@ -120,6 +120,13 @@ static int gaussian_cached(double sigma, GaussianK &out)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// shapes the packed-length kernels (strip / tile / lean) take: 32-bit byte offsets inside a plane, and row indices that the tile
+// kernel multiplies with 24-bit multiplies (an image of 2 x 10 000 000 pixels passes the first test only)
+static inline bool packed_dims_ok(int H, int W)
+{
+	return (int64_t)H * W < ((int64_t)1 << 29) - 4096 && H < (1 << 23) - 64 && W < (1 << 23) - 256;
+}
+
 // One aggregation pass over packed arm lengths (cbca_pack).  max_arm = the largest arm that can occur (L1 - 1 where L1 is
 // known, < 0 where it is not: adcensus.cbca).  Arms <= 4: the tile kernel's short-arm instance.  Otherwise the pair's
 // route word (cbca_pack: arm classes actually present, share of pixels with unit arms) decides on the device between the
@@ -297,7 +304,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	const int nvol = (p->left_only && !p->lr_check && !volR_out && !dispR0_out) ? 1 : 2;
 	// n CBCA iterations on the (D,H,W) volumes, ping-pong between the two buffers of each side (instead of vol:copy(tmp))
 	auto cbca_iterations = [&](int n) -> int {
-		const bool packed_ok = cbca_cap <= 254 && HW < ((int64_t)1 << 29) - 4096;  // packed lengths saturate at 255
+		const bool packed_ok = cbca_cap <= 254 && packed_dims_ok(H, W);  // packed lengths saturate at 255
 		for (int i = 0; i < n; ++i) {
 			for (int v = 0; v < nvol; ++v) {
 				float *dst = other(v);
@@ -602,8 +609,9 @@ int mc_cbca_ws(const float *x0c, const float *x1c, const float *vol_in, float *v
 	MC_REQUIRE(scratch_bytes >= cbca_scratch_bytes(H, W), "mc_cbca_ws: scratch holds %zu bytes, needs %zu", scratch_bytes,
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws: scratch must be 4-byte aligned");
-	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws: image too large for 32-bit plane offsets (use mc_cbca)");
 	hipStream_t st = as_stream(stream);
+	if (!packed_dims_ok(H, W))   // (huge or extremely elongated images: one thread per voxel, 64-bit offsets)
+		return cbca(x0c, x1c, vol_in, vol_out, D, H, W, direction, st);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
 	rc = cbca_by_arms(scratch, vol_in, vol_out, D, H, W, direction, -1, st);
@@ -627,7 +635,7 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	MC_REQUIRE(scratch_bytes >= cbca_scratch_bytes(H, W), "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu", scratch_bytes,
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
-	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) - 4096, "mc_cbca_ws_cfg: image too large for 32-bit plane offsets");
+	MC_REQUIRE(packed_dims_ok(H, W), "mc_cbca_ws_cfg: image too large for the packed-length kernels (32-bit plane offsets, 24-bit row indices)");
 	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 9, "mc_cbca_ws_cfg: bad rb / nt / form");
 	MC_REQUIRE(d0 >= 0 && nd >= 0 && (form >= 8 || d0 + nd <= D), "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
 	hipStream_t st = as_stream(stream);

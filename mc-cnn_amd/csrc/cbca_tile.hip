@@ -188,6 +188,18 @@ __device__ __forceinline__ void tile_taps3_p(float (&v)[9], unsigned pa, int n, 
 
 }  // namespace
 
+// head of the plan (256 bytes): who wrote it.  A pass that reads a plan stands down unless it was written for exactly this
+// problem, direction and arm class (a reading call without its writing call, or on a cached scratch of another shape)
+constexpr int PLAN_HDR = 256;
+enum { PH_MAGIC = 0, PH_D = 1, PH_H = 2, PH_W = 3, PH_DIR = 4, PH_ARM = 5 };
+constexpr uint32_t PH_MAGIC_VALUE = 0x504c414eu;
+__device__ __forceinline__ bool plan_valid(const CbcaArgs &P, int arm_class)
+{
+	const uint32_t *__restrict__ h = (const uint32_t *)P.plan;
+	return h[PH_MAGIC] == PH_MAGIC_VALUE && h[PH_D] == (uint32_t)P.D && h[PH_H] == (uint32_t)P.H && h[PH_W] == (uint32_t)P.W &&
+	       h[PH_DIR] == (uint32_t)(P.direction + 1) && h[PH_ARM] == (uint32_t)arm_class;
+}
+
 // item i = (column c, row group g): outputs window rows A + 4g .. A + 4g + 3 of column c; height = rows from the topmost
 // first row to the bottommost last row of its outputs that have a partner.  Window rows 0 .. (ring rows) - 1, ring slot of
 // window row w = (base + w) mod RR.
@@ -481,6 +493,12 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	cb_u32 *__restrict__ CTRl = GHl + (MODE == 2 ? 0 : NG * NKEY);   // [0] next chunk
 
 	if (!cbca_gate(P.flags, P.route)) return;   // (the pair's arms call for another kernel)
+	if (MODE == 2 && !plan_valid(P, A)) return;   // (not this problem's plan)
+	if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+		uint32_t *h = (uint32_t *)P.plan;
+		h[PH_D] = (uint32_t)P.D; h[PH_H] = (uint32_t)P.H; h[PH_W] = (uint32_t)P.W; h[PH_DIR] = (uint32_t)(P.direction + 1); h[PH_ARM] = (uint32_t)A;
+		h[PH_MAGIC] = PH_MAGIC_VALUE;
+	}
 	const int tid0 = threadIdx.x;
 	const int tid = tid0, lane = tid & 63;
 	const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: per-row store descriptors stay in SGPRs
@@ -510,7 +528,7 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	constexpr int ENT = G::ENT_BYTES;
 	const int nsteps = (ye - ys + TH - 1) / TH;
 	const __amdgpu_buffer_rsrc_t rplan = __builtin_amdgcn_make_buffer_rsrc(
-		MODE ? (void *)((char *)P.plan + ((size_t)d * (size_t)(P.gx * P.gy) + (size_t)region) * (size_t)P.spr * ENT) : nullptr, 0, MODE ? P.spr * ENT : 0, 0x00020000);
+		MODE ? (void *)((char *)P.plan + PLAN_HDR + ((size_t)d * (size_t)(P.gx * P.gy) + (size_t)region) * (size_t)P.spr * ENT) : nullptr, 0, MODE ? P.spr * ENT : 0, 0x00020000);
 
 	// ... and behind the tables, per plane, the combined runs (2 bytes per pixel) and vertical arms (1 byte) exactly as the
 	// first pass committed them to its ring: rows of Wp = W rounded up to whole tiles
@@ -769,10 +787,10 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 			}
 		} else {
 			const cb_u32 *hdr = (const cb_u32 *)(TABl + NI);
-			nz = min(__builtin_amdgcn_readfirstlane((int)hdr[0]), NI);   // (clamped: an entry nobody wrote must not turn into a long loop)
-			nfast = __builtin_amdgcn_readfirstlane((int)hdr[1]);
-			ngen = __builtin_amdgcn_readfirstlane((int)hdr[2]);
-			ntall = min(__builtin_amdgcn_readfirstlane((int)hdr[3]), nz);
+			nz = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[0]), NI));   // (clamped: an entry nobody wrote must not turn into a long loop)
+			nfast = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[1]), nz));
+			ngen = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[2]), nfast));
+			ntall = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[3]), nz));
 		}
 		// A step's tallest chunk is one wave walking a chain of thousands of instructions while the block's other waves wait at
 		// the barrier.  Where a step has only a few tall items (flat regions entering the tile) they are taken apart instead: a
@@ -857,18 +875,20 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 // done[4], cumulative unit counts[4]): LDS operations of a CU are served in issue order, so "data, wait, flag" on one side and "flag,
 // data" on the other is all the ordering there is; spins are bounded (a wave that gives up raises the abort word and every wave leaves).
 template <int A, int TW, int TH, int NCW, bool NT>
-__global__ void __launch_bounds__(64 * (NCW + 1), (2 * (NCW + 1) + 3) / 4) cbca_roll_kernel(const CbcaArgs P)
+__global__ void __launch_bounds__(64 * (NCW + 2), (2 * (NCW + 2) + 3) / 4) cbca_roll_kernel(const CbcaArgs P)
 {
 	using G = TileGeo<A, TW, TH, 2>;
 	constexpr int AH = G::AH, SW = G::SW, NI = G::NI;
 	constexpr int RR = 2 * TH + 2 * A;              // ring rows: the windows of two consecutive steps
-	constexpr int NTHREADS = 64 * (NCW + 1);
+	constexpr int NMV = 2;                          // mover waves: each owns half of a step's rows (so that a step's rows in flight fit their registers)
+	constexpr int NTHREADS = 64 * (NCW + NMV);
 	constexpr int VOL_AUX = NT ? 2 : 0;
 	constexpr int NSPLIT_MAX = MC_TILE_NSPLIT;
 	constexpr bool PIPE = true;
 	constexpr int V_BYTES = RR * SW * 4, M_BYTES = (RR * TW * 2 + 15) & ~15, UD_BYTES = (RR * TW + 15) & ~15;
 	constexpr int OUT1 = TH * TW, TAB1 = G::TAB_BYTES / 2;   // words of one result tile / u16 of one item table
-	static_assert(G::TAB_BYTES % 16 == 0 && TW % 64 == 0 && TH % 4 == 0 && TW * 2 % 16 == 0, "roll geometry");
+	constexpr int HR = TH / NMV;                             // rows of a step per mover
+	static_assert(G::TAB_BYTES % 16 == 0 && TW % 64 == 0 && TH % (4 * NMV) == 0 && TW * 2 % 16 == 0 && TW / 4 == 32, "roll geometry");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	float *__restrict__ Vl = (float *)smem;
 	unsigned short *__restrict__ Ml = (unsigned short *)(smem + V_BYTES);
@@ -876,9 +896,9 @@ __global__ void __launch_bounds__(64 * (NCW + 1), (2 * (NCW + 1) + 3) / 4) cbca_
 	float *__restrict__ OUTl = (float *)(smem + V_BYTES + M_BYTES + UD_BYTES);                                  // two tiles: step s uses s & 1
 	unsigned short *__restrict__ TABl = (unsigned short *)(smem + V_BYTES + M_BYTES + UD_BYTES + 2 * OUT1 * 4);   // two tables
 	cb_u32 *__restrict__ CT = (cb_u32 *)(smem + V_BYTES + M_BYTES + UD_BYTES + 2 * OUT1 * 4 + 2 * G::TAB_BYTES);
-	enum { C_TICKET = 0, C_READY = 1, C_ABORT = 2, C_DONE = 4, C_NUN = 8, C_CUM = 16, C_WORDS = 24 };   // done / units per step: 4 slots, cumulative units: 8
+	enum { C_TICKET = 0, C_READY = 1, C_ABORT = 2, C_MOVERS = 3, C_DONE = 4, C_NUN = 8, C_CUM = 16, C_WORDS = 24 };   // done / units per step: 4 slots, cumulative units: 8
 
-	if (!cbca_gate(P.flags, P.route)) return;
+	if (!cbca_gate(P.flags, P.route) || !plan_valid(P, A)) return;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int H = P.H, W = P.W;
@@ -899,76 +919,83 @@ __global__ void __launch_bounds__(64 * (NCW + 1), (2 * (NCW + 1) + 3) / 4) cbca_
 	constexpr int ENT = G::ENT_BYTES;
 	const int nsteps = (ye - ys + TH - 1) / TH;
 	const __amdgpu_buffer_rsrc_t rplan = __builtin_amdgcn_make_buffer_rsrc(
-		(void *)((char *)P.plan + ((size_t)d * (size_t)(P.gx * P.gy) + (size_t)region) * (size_t)P.spr * ENT), 0, P.spr * ENT, 0x00020000);
+		(void *)((char *)P.plan + PLAN_HDR + ((size_t)d * (size_t)(P.gx * P.gy) + (size_t)region) * (size_t)P.spr * ENT), 0, P.spr * ENT, 0x00020000);
 	const int Wp = P.wp;
 	const __amdgpu_buffer_rsrc_t rpm = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)P.plan + P.plan_m + (size_t)d * H * Wp * 2), 0, H * Wp * 2, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rpu = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)P.plan + P.plan_ud + (size_t)d * H * Wp), 0, H * Wp, 0x00020000);
 	const int ylast = min(H, ye + A);
 
-	// ---- one step's rows: values (16-byte units of 4 columns, all staged columns), runs (units of 8 pixels) and vertical arms (units of 16
-	// pixels) of the output columns, the step's item table (65 units).  NT threads share the work; rows outside the image: zeros / "no output".
+	// ---- a row's pieces: values (16-byte units of 4 columns, all staged columns), runs (units of 8 pixels) and vertical arms (units of
+	// 16 pixels) of the output columns; a step's item table (65 units).  Rows outside the image: zeros / "no output".
 	constexpr int UPR = SW / 4, MPR = TW / 8, UPRD = TW / 16, TABU = G::TAB_BYTES / 16;
-	auto v_off = [&](int rr, int u) -> cb_u32 {   // relative row rr (image row yr0 + rr), value unit u
-		const int y = yr0 + rr;
-		return (y >= 0 && y < ylast) ? (cb_u32)(y * W + sx0 + 4 * u) * 4u : OOB;   // (as in cbca_tile_kernel: one 16-byte load wherever the unit starts)
-	};
-	auto commit_v = [&](const cb_u4 &v, int rr, int u) {
-		const int slot = rr % RR;
-		*(cb_u4 *)(Vl + slot * SW + 4 * u) = v;
-	};
-	auto commit_m = [&](cb_u4 m, int rr, int u) {
-		const int y = yr0 + rr;
-		if (!(y >= 0 && y < ylast)) m = cb_u4{0u, 0u, 0u, 0u};
-		*(cb_u4 *)(Ml + (rr % RR) * TW + 8 * u) = m;
-	};
-	auto commit_ud = [&](cb_u4 ud, int rr, int u) {
-		const int y = yr0 + rr;
-		if (!(y >= 0 && y < ylast)) ud = cb_u4{~0u, ~0u, ~0u, ~0u};
-		*(cb_u4 *)(UDl + (rr % RR) * TW + 16 * u) = ud;
-	};
-	auto m_off = [&](int rr, int u) -> cb_u32 {
-		const int y = yr0 + rr;
-		return (y >= 0 && y < ylast) ? (cb_u32)(y * Wp + tx0 + 8 * u) * 2u : OOB;
-	};
-	auto ud_off = [&](int rr, int u) -> cb_u32 {
-		const int y = yr0 + rr;
-		return (y >= 0 && y < ylast) ? (cb_u32)(y * Wp + tx0 + 16 * u) : OOB;
-	};
-	// outputs without a partner are copied through (adcensus.cu:353-354): whole columns of tiles that reach beyond [lo, lo + span)
-	auto copy_through = [&](int s, int t0, int nt) {
+	auto row_in = [&](int rr) -> bool { const int y = yr0 + rr; return y >= 0 && y < ylast; };
+	// (values: one 16-byte load wherever the unit starts, as in cbca_tile_kernel)
+	auto v_off = [&](int rr, int u) -> cb_u32 { return row_in(rr) ? (cb_u32)((yr0 + rr) * W + sx0 + 4 * u) * 4u : OOB; };
+	auto m_off = [&](int rr, int u) -> cb_u32 { return row_in(rr) ? (cb_u32)((yr0 + rr) * Wp + tx0 + 8 * u) * 2u : OOB; };
+	auto ud_off = [&](int rr, int u) -> cb_u32 { return row_in(rr) ? (cb_u32)((yr0 + rr) * Wp + tx0 + 16 * u) : OOB; };
+	// outputs without a partner are copied through (adcensus.cu:353-354): whole columns of tiles that reach beyond [lo, lo + span);
+	// rows r0 .. r0 + nr - 1 of step s's tile, slot0 = ring slot of the step's first OUTPUT row
+	auto copy_through = [&](int s, int slot0, int r0, int nr, int t0, int nt) {
 		if (!edge_tile) return;
-		for (int q = t0; q < TH * TW; q += nt) {
-			const int r = q / TW, cc = q - r * TW;
-			if ((cb_u32)(tx0 + cc - lo) >= span) OUTl[(s & 1) * OUT1 + q] = Vl[((s * TH + A + r) % RR) * SW + AH + cc];
+		for (int q = t0; q < nr * TW; q += nt) {
+			const int r = r0 + q / TW, cc = q % TW;
+			int slot = slot0 + r;
+			slot = slot >= RR ? slot - RR : slot;
+			if ((cb_u32)(tx0 + cc - lo) >= span) OUTl[(s & 1) * OUT1 + r * TW + cc] = Vl[slot * SW + AH + cc];
 		}
 	};
 	auto units_of = [&](cb_u32 nz, cb_u32 ntall) -> int {   // work units of a step (as cbca_tile_kernel)
-		const int z = min((int)nz, NI), t = min((int)ntall, z);
+		const int z = max(0, min((int)nz, NI)), t = max(0, min((int)ntall, z));
 		const int nsplit = (A > 4 && t <= NSPLIT_MAX) ? t : 0;
 		return ((nsplit + 15) >> 4) + ((z - nsplit + 63) >> 6);
 	};
 
-	// ---- prologue, all waves: the windows of steps 0 and 1 (relative rows 0 .. RR - 1), their tables
-	for (int q = tid; q < RR * UPR; q += NTHREADS) {
-		const int rr = q / UPR, u = q - rr * UPR;
-		commit_v(__builtin_amdgcn_raw_buffer_load_b128(rv, v_off(rr, u), 0, VOL_AUX), rr, u);
+	// ---- prologue, all waves: the windows of steps 0 and 1 (relative rows 0 .. RR - 1 = ring slots 0 .. RR - 1) and their tables; every
+	// request first, then the commits (one memory round trip)
+	{
+		constexpr int PV = (RR * UPR + NTHREADS - 1) / NTHREADS, PM = (RR * MPR + NTHREADS - 1) / NTHREADS, PU = (RR * UPRD + NTHREADS - 1) / NTHREADS;
+		static_assert(2 * TABU <= NTHREADS, "one table unit per thread");
+		cb_u4 pv[PV], pm[PM], pu[PU], pt;
+#pragma unroll
+		for (int k = 0; k < PV; ++k) {
+			const int q = tid + k * NTHREADS, rr = q / UPR, u = q - rr * UPR;
+			pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, q < RR * UPR ? v_off(rr, u) : OOB, 0, VOL_AUX);
+		}
+#pragma unroll
+		for (int k = 0; k < PM; ++k) {
+			const int q = tid + k * NTHREADS, rr = q / MPR, u = q - rr * MPR;
+			pm[k] = __builtin_amdgcn_raw_buffer_load_b128(rpm, q < RR * MPR ? m_off(rr, u) : OOB, 0, 0);
+		}
+#pragma unroll
+		for (int k = 0; k < PU; ++k) {
+			const int q = tid + k * NTHREADS, rr = q / UPRD, u = q - rr * UPRD;
+			pu[k] = __builtin_amdgcn_raw_buffer_load_b128(rpu, q < RR * UPRD ? ud_off(rr, u) : OOB, 0, 0);
+		}
+		{
+			const int s = tid / TABU, u = tid - s * TABU;
+			pt = __builtin_amdgcn_raw_buffer_load_b128(rplan, (tid < 2 * TABU && s < nsteps) ? (cb_u32)(s * ENT + u * 16) : OOB, 0, 0);
+		}
+#pragma unroll
+		for (int k = 0; k < PV; ++k) {
+			const int q = tid + k * NTHREADS, rr = q / UPR, u = q - rr * UPR;
+			if (q < RR * UPR) *(cb_u4 *)(Vl + rr * SW + 4 * u) = pv[k];
+		}
+#pragma unroll
+		for (int k = 0; k < PM; ++k) {
+			const int q = tid + k * NTHREADS, rr = q / MPR, u = q - rr * MPR;
+			if (q < RR * MPR) *(cb_u4 *)(Ml + rr * TW + 8 * u) = row_in(rr) ? pm[k] : cb_u4{0u, 0u, 0u, 0u};
+		}
+#pragma unroll
+		for (int k = 0; k < PU; ++k) {
+			const int q = tid + k * NTHREADS, rr = q / UPRD, u = q - rr * UPRD;
+			if (q < RR * UPRD) *(cb_u4 *)(UDl + rr * TW + 16 * u) = row_in(rr) ? pu[k] : cb_u4{~0u, ~0u, ~0u, ~0u};
+		}
+		if (tid < 2 * TABU) *(cb_u4 *)(TABl + (tid / TABU) * TAB1 + 8 * (tid % TABU)) = pt;
+		if (tid < C_WORDS) CT[tid] = 0;
 	}
-	for (int q = tid; q < RR * MPR; q += NTHREADS) {
-		const int rr = q / MPR, u = q - rr * MPR;
-		commit_m(__builtin_amdgcn_raw_buffer_load_b128(rpm, m_off(rr, u), 0, 0), rr, u);
-	}
-	for (int q = tid; q < RR * UPRD; q += NTHREADS) {
-		const int rr = q / UPRD, u = q - rr * UPRD;
-		commit_ud(__builtin_amdgcn_raw_buffer_load_b128(rpu, ud_off(rr, u), 0, 0), rr, u);
-	}
-	for (int q = tid; q < 2 * TABU; q += NTHREADS) {
-		const int s = q / TABU, u = q - s * TABU;
-		*(cb_u4 *)(TABl + s * TAB1 + 8 * u) = __builtin_amdgcn_raw_buffer_load_b128(rplan, s < nsteps ? (cb_u32)(s * ENT + u * 16) : OOB, 0, 0);
-	}
-	if (tid < C_WORDS) CT[tid] = 0;
 	__syncthreads();
-	copy_through(0, tid, NTHREADS);
-	if (nsteps > 1) copy_through(1, tid, NTHREADS);
+	copy_through(0, A, 0, TH, tid, NTHREADS);
+	if (nsteps > 1) copy_through(1, TH + A, 0, TH, tid, NTHREADS);
 	if (tid == 0) {
 		const cb_u32 *h0 = (const cb_u32 *)(TABl + NI), *h1 = (const cb_u32 *)(TABl + TAB1 + NI);
 		const int n0 = units_of(h0[0], h0[3]), n1 = nsteps > 1 ? units_of(h1[0], h1[3]) : 0;
@@ -979,13 +1006,14 @@ __global__ void __launch_bounds__(64 * (NCW + 1), (2 * (NCW + 1) + 3) / 4) cbca_
 	__syncthreads();
 
 	auto lds_word = [&](int i) -> cb_u32 { return __hip_atomic_load(CT + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+	auto lds_set = [&](int i, cb_u32 v) { __hip_atomic_store(CT + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 	constexpr int SPIN_LIMIT = 1 << 22;   // (x 64-clock sleeps: ~0.1 s -- far beyond any step; a wave that gets here gives up for the block)
 	// spins until word i >= need (true) or the block is aborting (false)
 	auto wait_ge = [&](int i, cb_u32 need) -> bool {
 		for (int spins = 0;; ++spins) {
 			if (lds_word(i) >= need) break;
 			if (lds_word(C_ABORT)) return false;
-			if (spins > SPIN_LIMIT) { __hip_atomic_store(CT + C_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return false; }
+			if (spins > SPIN_LIMIT) { lds_set(C_ABORT, 1u); return false; }
 			__builtin_amdgcn_s_sleep(1);
 		}
 		asm volatile("" ::: "memory");
@@ -1012,10 +1040,10 @@ __global__ void __launch_bounds__(64 * (NCW + 1), (2 * (NCW + 1) + 3) / 4) cbca_
 			if (!alive) break;
 			const int unit = (int)(g - cum0);
 			const cb_u32 *hdr = (const cb_u32 *)(TABl + (cs & 1) * TAB1 + NI);
-			const int nz = min(__builtin_amdgcn_readfirstlane((int)hdr[0]), NI);
-			const int nfast = __builtin_amdgcn_readfirstlane((int)hdr[1]);
-			const int ngen = __builtin_amdgcn_readfirstlane((int)hdr[2]);
-			const int ntall = min(__builtin_amdgcn_readfirstlane((int)hdr[3]), nz);
+			const int nz = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[0]), NI));
+			const int nfast = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[1]), nz));
+			const int ngen = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[2]), nfast));
+			const int ntall = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[3]), nz));
 			const int nsplit = (A > 4 && ntall <= NSPLIT_MAX) ? ntall : 0;
 			const int usplit = (nsplit + 15) >> 4;
 			tile_unit<A, TW, SW, RR, PIPE>(unit, lane, Vl, Ml, UDl, OUTl + (cs & 1) * OUT1, TABl + (cs & 1) * TAB1, base, nz, nfast, ngen, nsplit, usplit);
@@ -1025,89 +1053,122 @@ __global__ void __launch_bounds__(64 * (NCW + 1), (2 * (NCW + 1) + 3) / 4) cbca_
 		return;
 	}
 
-	// ================= mover =================
-	constexpr int NV = (TH * UPR + 63) / 64, NM = (TH * MPR + 63) / 64, NU = (TH * UPRD + 63) / 64, NT_ = (TABU + 63) / 64;
-	struct Rows { cb_u4 v[NV], m[NM], ud[NU], tab[NT_]; } R;
-	// requests the rows step s adds to the ring (relative rows s TH + 2A .. + TH - 1; s >= 2) and its table
-	auto fetch_step = [&](int s) {
+	// ================= movers: mover mv owns rows mv HR .. mv HR + HR - 1 of every step (mover 0 also the item table) =================
+	const int mv = wvs - NCW;
+	__builtin_amdgcn_s_setprio(3);   // (few instructions, but every step waits for them)
+	constexpr int NV = (HR * UPR + 63) / 64, NM = (HR * MPR + 63) / 64, NU = (HR * UPRD + 63) / 64, NTB = (TABU + 63) / 64;
+	struct Rows { cb_u4 v[NV], m[NM], ud[NU], tab[NTB]; } R;
+	// requests this mover's rows of what step s adds to the ring (relative rows s TH + 2A + mv HR ..; s >= 2) and the step's table
+	auto fetch_step = [&](int s, int lane) {
 		const bool on = s < nsteps;
-		const int rr0 = s * TH + 2 * A;
+		const int rr0 = s * TH + 2 * A + mv * HR;
 #pragma unroll
 		for (int k = 0; k < NV; ++k) {
 			const int q = lane + 64 * k, r = q / UPR, u = q - r * UPR;
-			R.v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, (on && r < TH) ? v_off(rr0 + r, u) : OOB, 0, VOL_AUX);
+			R.v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, (on && r < HR) ? v_off(rr0 + r, u) : OOB, 0, VOL_AUX);
 		}
 #pragma unroll
 		for (int k = 0; k < NM; ++k) {
 			const int q = lane + 64 * k, r = q / MPR, u = q - r * MPR;
-			R.m[k] = __builtin_amdgcn_raw_buffer_load_b128(rpm, (on && r < TH) ? m_off(rr0 + r, u) : OOB, 0, 0);
+			R.m[k] = __builtin_amdgcn_raw_buffer_load_b128(rpm, (on && r < HR) ? m_off(rr0 + r, u) : OOB, 0, 0);
 		}
 #pragma unroll
 		for (int k = 0; k < NU; ++k) {
 			const int q = lane + 64 * k, r = q / UPRD, u = q - r * UPRD;
-			R.ud[k] = __builtin_amdgcn_raw_buffer_load_b128(rpu, (on && r < TH) ? ud_off(rr0 + r, u) : OOB, 0, 0);
+			R.ud[k] = __builtin_amdgcn_raw_buffer_load_b128(rpu, (on && r < HR) ? ud_off(rr0 + r, u) : OOB, 0, 0);
 		}
 #pragma unroll
-		for (int k = 0; k < NT_; ++k) {
+		for (int k = 0; k < NTB; ++k) {
 			const int q = lane + 64 * k;
-			R.tab[k] = __builtin_amdgcn_raw_buffer_load_b128(rplan, (on && q < TABU) ? (cb_u32)(s * ENT + q * 16) : OOB, 0, 0);
+			R.tab[k] = __builtin_amdgcn_raw_buffer_load_b128(rplan, (on && mv == 0 && q < TABU) ? (cb_u32)(s * ENT + q * 16) : OOB, 0, 0);
 		}
 	};
-	auto commit_step = [&](int s) {
-		const int rr0 = s * TH + 2 * A;
+	// ... into the ring: slot0 = ring slot of relative row s TH + 2A (= the slot of step s - 2's first window row)
+	auto commit_step = [&](int s, int slot0, int lane) {
+		const int rr0 = s * TH + 2 * A + mv * HR;
+		auto slot_of = [&](int r) { int t = slot0 + mv * HR + r; return t >= RR ? t - RR : t; };
 #pragma unroll
 		for (int k = 0; k < NV; ++k) {
 			const int q = lane + 64 * k, r = q / UPR, u = q - r * UPR;
-			if (r < TH) commit_v(R.v[k], rr0 + r, u);
+			if (r < HR) *(cb_u4 *)(Vl + slot_of(r) * SW + 4 * u) = R.v[k];
 		}
 #pragma unroll
 		for (int k = 0; k < NM; ++k) {
 			const int q = lane + 64 * k, r = q / MPR, u = q - r * MPR;
-			if (r < TH) commit_m(R.m[k], rr0 + r, u);
+			if (r < HR) *(cb_u4 *)(Ml + slot_of(r) * TW + 8 * u) = row_in(rr0 + r) ? R.m[k] : cb_u4{0u, 0u, 0u, 0u};
 		}
 #pragma unroll
 		for (int k = 0; k < NU; ++k) {
 			const int q = lane + 64 * k, r = q / UPRD, u = q - r * UPRD;
-			if (r < TH) commit_ud(R.ud[k], rr0 + r, u);
+			if (r < HR) *(cb_u4 *)(UDl + slot_of(r) * TW + 16 * u) = row_in(rr0 + r) ? R.ud[k] : cb_u4{~0u, ~0u, ~0u, ~0u};
 		}
+		if (mv == 0) {
 #pragma unroll
-		for (int k = 0; k < NT_; ++k) {
-			const int q = lane + 64 * k;
-			if (q < TABU) *(cb_u4 *)(TABl + (s & 1) * TAB1 + 8 * q) = R.tab[k];
+			for (int k = 0; k < NTB; ++k) {
+				const int q = lane + 64 * k;
+				if (q < TABU) *(cb_u4 *)(TABl + (s & 1) * TAB1 + 8 * q) = R.tab[k];
+			}
 		}
 	};
-	fetch_step(2);
-	cb_u32 cum = lds_word(C_CUM + 1);
+	fetch_step(2, lane);
+	cb_u32 cum = lds_word(C_CUM + 1);   // (kept by both movers; the one that announces a step publishes it)
+	int slot0 = 0;                      // ring slot of step s's first window row
+	constexpr int OPR = TW / 4;         // 16-byte units of a tile row: 32, two rows per wave-wide read
 	for (int s = 0; s < nsteps; ++s) {
 		if (!wait_ge(C_DONE + (s & 3), lds_word(C_NUN + (s & 3)))) return;
-		// step s is complete: its tile leaves as rows (a row per instruction: the descriptor ends with the row, so that the words
-		// of a last unit beyond the image are dropped by the range check; rows beyond the region get an empty descriptor)
-		constexpr int OPR = TW / 4;
-		static_assert(OPR <= 64, "a row is one store instruction");
-#pragma unroll 4
-		for (int r = 0; r < TH; ++r) {
-			const int y = ys + s * TH + r;
-			const cb_f4 ov = *(const cb_f4 *)(OUTl + (s & 1) * OUT1 + r * TW + 4 * (lane < OPR ? lane : 0));
-			const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(P.vout + (size_t)d * HWi), 0, y < ye ? (y + 1) * W * 4 : 0, 0x00020000);
-			__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(ov.x), __float_as_uint(ov.y), __float_as_uint(ov.z), __float_as_uint(ov.w)}, rrow,
-			                                       lane < OPR ? (cb_u32)(y * W + tx0 + 4 * lane) * 4u : OOB, 0, VOL_AUX);
-		}
-		if (lane == 0) __hip_atomic_store(CT + C_DONE + (s & 3), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		int ln = lane;
+		asm volatile("" : "+v"(ln));   // (opaque: the per-lane index arithmetic of commit / requests is redone per step instead of living in registers)
+		// step s is complete.  This mover's rows of its tile -> registers (two rows per read: lanes 0-31 / 32-63)
+		cb_f4 ov[HR / 2];
+#pragma unroll
+		for (int k = 0; k < HR / 2; ++k) ov[k] = *(const cb_f4 *)(OUTl + (s & 1) * OUT1 + (mv * HR + 2 * k + (lane >> 5)) * TW + 4 * (lane & (OPR - 1)));
+		int nun = 0;
+		bool announced = false;
 		if (s + 2 < nsteps) {
-			commit_step(s + 2);   // (waits for the rows requested a step ago) over step s's oldest TH rows and its table
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-			copy_through(s + 2, lane, 64);
-			const cb_u32 *h = (const cb_u32 *)(TABl + (s & 1) * TAB1 + NI);
-			const int nun = units_of(h[0], h[3]);
-			cum += (cb_u32)nun;
-			if (lane == 0) {
-				CT[C_NUN + ((s + 2) & 3)] = (cb_u32)nun;
-				CT[C_CUM + ((s + 2) & 7)] = cum;
-			}
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // rows, table, tile columns and counts before the step is announced
-			if (lane == 0) __hip_atomic_store(CT + C_READY, (cb_u32)(s + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			commit_step(s + 2, slot0, ln);   // (waits for the rows requested a step ago) over step s's oldest TH rows, and the table
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (tile rows read, ring rows written)
 		}
-		fetch_step(s + 3);
+		// the movers meet: the last one to arrive announces the step (it sees the other's rows, and the table)
+		cb_u32 arrived = 0;
+		if (lane == 0) arrived = atomicAdd(CT + C_MOVERS, 1u);
+		arrived = (cb_u32)__builtin_amdgcn_readfirstlane((int)arrived);
+		if (s + 2 < nsteps && arrived == (cb_u32)(NMV * (s + 1) - 1)) {   // (the counter only grows: NMV arrivals per step, and no mover starts
+			asm volatile("" ::: "memory");                                  // step s + 1 before step s + 2 has been announced: see the end of the loop)
+			int oslot = slot0 + A;       // ring slot of step s + 2's first output row: relative row (s + 2) TH + A
+			oslot = oslot + 2 * TH >= RR ? oslot + 2 * TH - RR : oslot + 2 * TH;
+			copy_through(s + 2, oslot, 0, TH, lane, 64);   // (reads rows both movers have just committed)
+			const cb_u32 *h = (const cb_u32 *)(TABl + (s & 1) * TAB1 + NI);
+			nun = units_of(h[0], h[3]);
+			if (lane == 0) {
+				lds_set(C_DONE + (s & 3), 0u);
+				CT[C_NUN + ((s + 2) & 3)] = (cb_u32)nun;
+				CT[C_CUM + ((s + 2) & 7)] = cum + (cb_u32)nun;
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile columns and counts before the step is announced
+			if (lane == 0) lds_set(C_READY, (cb_u32)(s + 2));
+			announced = true;
+		}
+		// the tile's rows leave, then the rows of the step after next are requested
+#pragma unroll
+		for (int k = 0; k < HR / 2; ++k) {
+#pragma unroll
+			for (int hh = 0; hh < 2; ++hh) {   // a row per instruction (the other half wave is masked by its offset): the descriptor ends with
+				const int r = mv * HR + 2 * k + hh;   // the row, so that the words of a last unit beyond the image are dropped by the range check
+				const int y = ys + s * TH + r;
+				const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(P.vout + (size_t)d * HWi), 0, y < ye ? (y + 1) * W * 4 : 0, 0x00020000);
+				__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(ov[k].x), __float_as_uint(ov[k].y), __float_as_uint(ov[k].z), __float_as_uint(ov[k].w)}, rrow,
+				                                       (lane >> 5) == hh ? (cb_u32)(y * W + tx0 + 4 * (lane & (OPR - 1))) * 4u : OOB, 0, VOL_AUX);
+			}
+		}
+		if (s + 2 < nsteps) {   // both movers keep the cumulative count: the announcing one computed this step's units, the other waits for
+			if (!announced) {   // the announcement (so the movers are never a step apart) and reads them
+				if (!wait_ge(C_READY, (cb_u32)(s + 2))) return;
+				nun = (int)lds_word(C_NUN + ((s + 2) & 3));
+			}
+			cum += (cb_u32)nun;
+		}
+		fetch_step(s + 3, ln);
+		slot0 += TH; slot0 = slot0 >= RR ? slot0 - RR : slot0;
 	}
 }
 
@@ -1139,7 +1200,7 @@ static void tile_regions(int H, int W, int TW, int TH, int &gx, int &gy, int &rb
 #endif
 // the product's geometries (128 x 16 tiles for either arm class) share one plan layout
 constexpr int PLAN_TW = 128, PLAN_TH = 16;
-// [item tables: D x regions x steps per region entries | combined runs (D, H, Wp) u16 | vertical arms (D, H, Wp) u8], Wp = W rounded up to whole tiles
+// [header (PLAN_HDR) | item tables: D x regions x steps per region entries | combined runs (D, H, Wp) u16 | vertical arms (D, H, Wp) u8], Wp = W rounded up to whole tiles
 struct PlanLayout { size_t m, ud, total; int wp; };
 static PlanLayout plan_layout(int D, int H, int W)
 {
@@ -1147,7 +1208,7 @@ static PlanLayout plan_layout(int D, int H, int W)
 	tile_regions(H, W, PLAN_TW, PLAN_TH, gx, gy, rb);
 	PlanLayout L;
 	L.wp = gx * PLAN_TW;   // rows of whole tiles: a tile's 128 pixels of a row are two / one aligned 128-byte lines
-	L.m = ((size_t)D * gx * gy * (rb / PLAN_TH) * TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES + 255) / 256 * 256;
+	L.m = (PLAN_HDR + (size_t)D * gx * gy * (rb / PLAN_TH) * TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES + 255) / 256 * 256;
 	L.ud = L.m + ((size_t)D * H * L.wp * 2 + 255) / 256 * 256;
 	L.total = L.ud + (size_t)D * H * L.wp;
 	return L;
@@ -1177,7 +1238,7 @@ static int cbca_tiles_launch_mode(CbcaArgs P, bool nt, hipStream_t st)
 	return check_launch("cbca_tile");
 }
 
-// the plan-reading pass in its rolling form (cbca_roll_kernel): 8 compute waves + the mover, two blocks per CU
+// the plan-reading pass in its rolling form (cbca_roll_kernel): 8 compute waves + two movers, two blocks per CU
 template <int A, int TW, int TH>
 static int cbca_roll_launch(const CbcaArgs &P, bool nt, hipStream_t st)
 {
@@ -1198,8 +1259,8 @@ static int cbca_roll_launch(const CbcaArgs &P, bool nt, hipStream_t st)
 		set_error("cbca_roll: hipFuncSetAttribute(%d bytes of LDS): %s", LDS, hipGetErrorString(e));
 		return (int)e;
 	}
-	if (nt) hipLaunchKernelGGL(kern_nt, dim3((unsigned)blocks), dim3(64 * (NCW + 1)), LDS, st, P);
-	else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * (NCW + 1)), LDS, st, P);
+	if (nt) hipLaunchKernelGGL(kern_nt, dim3((unsigned)blocks), dim3(64 * (NCW + 2)), LDS, st, P);
+	else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * (NCW + 2)), LDS, st, P);
 	return check_launch("cbca_roll");
 }
 
