@@ -671,7 +671,6 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 		MC_REQUIRE((uintptr_t)scratch % 16 == 0, "mc_cbca_ws_cfg: scratch must be 16-byte aligned for the plan");
 		cfg.plan = (char *)scratch + off;
 		cfg.plan_mode = form <= 5 ? 1 : 2;
-		cfg.roll = form >= 6 ? (rb == 1 ? 1 : (rb == 2 ? 0 : -1)) : -1;   // (forms 6 / 7: rb = 1 the rolling form of the plan-reading pass, 2 the barrier form, 0 the product's choice)
 		const bool shortarm = form == 4 || form == 6;
 		return cbca_tiles(scratch, vol_in, vol_out, D, H, W, direction, shortarm ? 4 : 13, shortarm ? CR_ARMS_LE4 : CR_ARMS_LE13, st, cfg);
 	}

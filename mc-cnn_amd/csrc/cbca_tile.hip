@@ -857,321 +857,6 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	}
 }
 
-// =====================================================================================================
-// The plan-reading pass without a barrier per step ("rolling" form)
-// =====================================================================================================
-// What bounds cbca_tile_kernel<.., 2> on real-scene arms is the barrier behind a step's chunk phase: a step has 8 chunks for 8 waves,
-// the tallest one is a chain of thousands of instructions and the others wait for it (waves spend 55 % of their cycles waiting,
-// profiles/r03_cbca_tile_pmc_mb_natural.csv; scripts/model/tile_roll.py: 0.38 of the waves' time is work) -- and every wave then
-// executes the step's fixed part (commit, stores, requests: a fifth of all instructions).  Here the ring holds the windows of TWO
-// consecutive steps (2 TH + 2 A rows) and the block has one more wave, the MOVER, which owns everything that is not a chunk:
-//   compute waves   take work units -- global ticket numbers, in step order, tallest first inside a step -- as long as the unit's step
-//                   is READY, process them (tile_unit: the same walk as above) and count them DONE;
-//   mover           when step s is done: sends its result tile to memory, overwrites the step's oldest TH ring rows with the rows
-//                   step s + 2 adds (requested a step earlier into its registers, with the plan's runs / vertical arms / item table)
-//                   and publishes step s + 2 as ready.
-// So the compute waves run up to one step ahead of the slowest chunk instead of waiting for it (model: 0.73 of their time is work),
-// and the per-step fixed part is executed once, by a wave that has nothing else to do.  All hand-offs are LDS words (ticket, ready,
-// done[4], cumulative unit counts[4]): LDS operations of a CU are served in issue order, so "data, wait, flag" on one side and "flag,
-// data" on the other is all the ordering there is; spins are bounded (a wave that gives up raises the abort word and every wave leaves).
-template <int A, int TW, int TH, int NCW, bool NT>
-__global__ void __launch_bounds__(64 * (NCW + 2), (2 * (NCW + 2) + 3) / 4) cbca_roll_kernel(const CbcaArgs P)
-{
-	using G = TileGeo<A, TW, TH, 2>;
-	constexpr int AH = G::AH, SW = G::SW, NI = G::NI;
-	constexpr int RR = 2 * TH + 2 * A;              // ring rows: the windows of two consecutive steps
-	constexpr int NMV = 2;                          // mover waves: each owns half of a step's rows (so that a step's rows in flight fit their registers)
-	constexpr int NTHREADS = 64 * (NCW + NMV);
-	constexpr int VOL_AUX = NT ? 2 : 0;
-	constexpr int NSPLIT_MAX = MC_TILE_NSPLIT;
-	constexpr bool PIPE = true;
-	constexpr int V_BYTES = RR * SW * 4, M_BYTES = (RR * TW * 2 + 15) & ~15, UD_BYTES = (RR * TW + 15) & ~15;
-	constexpr int OUT1 = TH * TW, TAB1 = G::TAB_BYTES / 2;   // words of one result tile / u16 of one item table
-	constexpr int HR = TH / NMV;                             // rows of a step per mover
-	static_assert(G::TAB_BYTES % 16 == 0 && TW % 64 == 0 && TH % (4 * NMV) == 0 && TW * 2 % 16 == 0 && TW / 4 == 32, "roll geometry");
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	float *__restrict__ Vl = (float *)smem;
-	unsigned short *__restrict__ Ml = (unsigned short *)(smem + V_BYTES);
-	unsigned char *__restrict__ UDl = smem + V_BYTES + M_BYTES;
-	float *__restrict__ OUTl = (float *)(smem + V_BYTES + M_BYTES + UD_BYTES);                                  // two tiles: step s uses s & 1
-	unsigned short *__restrict__ TABl = (unsigned short *)(smem + V_BYTES + M_BYTES + UD_BYTES + 2 * OUT1 * 4);   // two tables
-	cb_u32 *__restrict__ CT = (cb_u32 *)(smem + V_BYTES + M_BYTES + UD_BYTES + 2 * OUT1 * 4 + 2 * G::TAB_BYTES);
-	enum { C_TICKET = 0, C_READY = 1, C_ABORT = 2, C_MOVERS = 3, C_DONE = 4, C_NUN = 8, C_CUM = 16, C_WORDS = 24 };   // done / units per step: 4 slots, cumulative units: 8
-
-	if (!cbca_gate(P.flags, P.route) || !plan_valid(P, A)) return;
-	const int tid = threadIdx.x, lane = tid & 63;
-	const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int H = P.H, W = P.W;
-	const int HWi = H * W;
-	const int xcd = blockIdx.x & 7, sblk = blockIdx.x >> 3;
-	const int region = (sblk / P.nd) * 8 + xcd;
-	const int d = P.d0 + sblk % P.nd;
-	if (region >= P.gx * P.gy) return;
-	const int cx = region % P.gx, cy = region / P.gx;
-	const int tx0 = cx * TW, ys = cy * P.rb, ye = min(H, ys + P.rb);
-	const int sh = d * P.direction;
-	const int sx0 = tx0 - AH, yr0 = ys - A;
-	const cb_u32 OOB = 0x80000000u;
-	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(P.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
-	const int lo = max(0, -sh);
-	const cb_u32 span = (cb_u32)max(0, min(W, W - sh) - lo);
-	const bool edge_tile = tx0 < lo || tx0 + TW > lo + (int)span;
-	constexpr int ENT = G::ENT_BYTES;
-	const int nsteps = (ye - ys + TH - 1) / TH;
-	const __amdgpu_buffer_rsrc_t rplan = __builtin_amdgcn_make_buffer_rsrc(
-		(void *)((char *)P.plan + PLAN_HDR + ((size_t)d * (size_t)(P.gx * P.gy) + (size_t)region) * (size_t)P.spr * ENT), 0, P.spr * ENT, 0x00020000);
-	const int Wp = P.wp;
-	const __amdgpu_buffer_rsrc_t rpm = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)P.plan + P.plan_m + (size_t)d * H * Wp * 2), 0, H * Wp * 2, 0x00020000);
-	const __amdgpu_buffer_rsrc_t rpu = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)P.plan + P.plan_ud + (size_t)d * H * Wp), 0, H * Wp, 0x00020000);
-	const int ylast = min(H, ye + A);
-
-	// ---- a row's pieces: values (16-byte units of 4 columns, all staged columns), runs (units of 8 pixels) and vertical arms (units of
-	// 16 pixels) of the output columns; a step's item table (65 units).  Rows outside the image: zeros / "no output".
-	constexpr int UPR = SW / 4, MPR = TW / 8, UPRD = TW / 16, TABU = G::TAB_BYTES / 16;
-	auto row_in = [&](int rr) -> bool { const int y = yr0 + rr; return y >= 0 && y < ylast; };
-	// (values: one 16-byte load wherever the unit starts, as in cbca_tile_kernel)
-	auto v_off = [&](int rr, int u) -> cb_u32 { return row_in(rr) ? (cb_u32)((yr0 + rr) * W + sx0 + 4 * u) * 4u : OOB; };
-	auto m_off = [&](int rr, int u) -> cb_u32 { return row_in(rr) ? (cb_u32)((yr0 + rr) * Wp + tx0 + 8 * u) * 2u : OOB; };
-	auto ud_off = [&](int rr, int u) -> cb_u32 { return row_in(rr) ? (cb_u32)((yr0 + rr) * Wp + tx0 + 16 * u) : OOB; };
-	// outputs without a partner are copied through (adcensus.cu:353-354): whole columns of tiles that reach beyond [lo, lo + span);
-	// rows r0 .. r0 + nr - 1 of step s's tile, slot0 = ring slot of the step's first OUTPUT row
-	auto copy_through = [&](int s, int slot0, int r0, int nr, int t0, int nt) {
-		if (!edge_tile) return;
-		for (int q = t0; q < nr * TW; q += nt) {
-			const int r = r0 + q / TW, cc = q % TW;
-			int slot = slot0 + r;
-			slot = slot >= RR ? slot - RR : slot;
-			if ((cb_u32)(tx0 + cc - lo) >= span) OUTl[(s & 1) * OUT1 + r * TW + cc] = Vl[slot * SW + AH + cc];
-		}
-	};
-	auto units_of = [&](cb_u32 nz, cb_u32 ntall) -> int {   // work units of a step (as cbca_tile_kernel)
-		const int z = max(0, min((int)nz, NI)), t = max(0, min((int)ntall, z));
-		const int nsplit = (A > 4 && t <= NSPLIT_MAX) ? t : 0;
-		return ((nsplit + 15) >> 4) + ((z - nsplit + 63) >> 6);
-	};
-
-	// ---- prologue, all waves: the windows of steps 0 and 1 (relative rows 0 .. RR - 1 = ring slots 0 .. RR - 1) and their tables; every
-	// request first, then the commits (one memory round trip)
-	{
-		constexpr int PV = (RR * UPR + NTHREADS - 1) / NTHREADS, PM = (RR * MPR + NTHREADS - 1) / NTHREADS, PU = (RR * UPRD + NTHREADS - 1) / NTHREADS;
-		static_assert(2 * TABU <= NTHREADS, "one table unit per thread");
-		cb_u4 pv[PV], pm[PM], pu[PU], pt;
-#pragma unroll
-		for (int k = 0; k < PV; ++k) {
-			const int q = tid + k * NTHREADS, rr = q / UPR, u = q - rr * UPR;
-			pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, q < RR * UPR ? v_off(rr, u) : OOB, 0, VOL_AUX);
-		}
-#pragma unroll
-		for (int k = 0; k < PM; ++k) {
-			const int q = tid + k * NTHREADS, rr = q / MPR, u = q - rr * MPR;
-			pm[k] = __builtin_amdgcn_raw_buffer_load_b128(rpm, q < RR * MPR ? m_off(rr, u) : OOB, 0, 0);
-		}
-#pragma unroll
-		for (int k = 0; k < PU; ++k) {
-			const int q = tid + k * NTHREADS, rr = q / UPRD, u = q - rr * UPRD;
-			pu[k] = __builtin_amdgcn_raw_buffer_load_b128(rpu, q < RR * UPRD ? ud_off(rr, u) : OOB, 0, 0);
-		}
-		{
-			const int s = tid / TABU, u = tid - s * TABU;
-			pt = __builtin_amdgcn_raw_buffer_load_b128(rplan, (tid < 2 * TABU && s < nsteps) ? (cb_u32)(s * ENT + u * 16) : OOB, 0, 0);
-		}
-#pragma unroll
-		for (int k = 0; k < PV; ++k) {
-			const int q = tid + k * NTHREADS, rr = q / UPR, u = q - rr * UPR;
-			if (q < RR * UPR) *(cb_u4 *)(Vl + rr * SW + 4 * u) = pv[k];
-		}
-#pragma unroll
-		for (int k = 0; k < PM; ++k) {
-			const int q = tid + k * NTHREADS, rr = q / MPR, u = q - rr * MPR;
-			if (q < RR * MPR) *(cb_u4 *)(Ml + rr * TW + 8 * u) = row_in(rr) ? pm[k] : cb_u4{0u, 0u, 0u, 0u};
-		}
-#pragma unroll
-		for (int k = 0; k < PU; ++k) {
-			const int q = tid + k * NTHREADS, rr = q / UPRD, u = q - rr * UPRD;
-			if (q < RR * UPRD) *(cb_u4 *)(UDl + rr * TW + 16 * u) = row_in(rr) ? pu[k] : cb_u4{~0u, ~0u, ~0u, ~0u};
-		}
-		if (tid < 2 * TABU) *(cb_u4 *)(TABl + (tid / TABU) * TAB1 + 8 * (tid % TABU)) = pt;
-		if (tid < C_WORDS) CT[tid] = 0;
-	}
-	__syncthreads();
-	copy_through(0, A, 0, TH, tid, NTHREADS);
-	if (nsteps > 1) copy_through(1, TH + A, 0, TH, tid, NTHREADS);
-	if (tid == 0) {
-		const cb_u32 *h0 = (const cb_u32 *)(TABl + NI), *h1 = (const cb_u32 *)(TABl + TAB1 + NI);
-		const int n0 = units_of(h0[0], h0[3]), n1 = nsteps > 1 ? units_of(h1[0], h1[3]) : 0;
-		CT[C_NUN + 0] = (cb_u32)n0; CT[C_NUN + 1] = (cb_u32)n1;
-		CT[C_CUM + 0] = (cb_u32)n0; CT[C_CUM + 1] = (cb_u32)(n0 + n1);
-		CT[C_READY] = (cb_u32)min(1, nsteps - 1);
-	}
-	__syncthreads();
-
-	auto lds_word = [&](int i) -> cb_u32 { return __hip_atomic_load(CT + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-	auto lds_set = [&](int i, cb_u32 v) { __hip_atomic_store(CT + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-	constexpr int SPIN_LIMIT = 1 << 22;   // (x 64-clock sleeps: ~0.1 s -- far beyond any step; a wave that gets here gives up for the block)
-	// spins until word i >= need (true) or the block is aborting (false)
-	auto wait_ge = [&](int i, cb_u32 need) -> bool {
-		for (int spins = 0;; ++spins) {
-			if (lds_word(i) >= need) break;
-			if (lds_word(C_ABORT)) return false;
-			if (spins > SPIN_LIMIT) { lds_set(C_ABORT, 1u); return false; }
-			__builtin_amdgcn_s_sleep(1);
-		}
-		asm volatile("" ::: "memory");
-		return true;
-	};
-
-	if (wvs < NCW) {
-		// ================= compute waves =================
-		int cs = 0, base = 0;     // the step this wave is at, ring slot of its first window row
-		cb_u32 cum0 = 0;          // units of the steps before cs
-		for (;;) {
-			cb_u32 g = 0;
-			if (lane == 0) g = atomicAdd(CT + C_TICKET, 1u);
-			g = (cb_u32)__builtin_amdgcn_readfirstlane((int)g);
-			bool alive = true;
-			for (;;) {   // the ticket's step
-				if (cs >= nsteps) { alive = false; break; }
-				if (!wait_ge(C_READY, (cb_u32)cs)) { alive = false; break; }
-				const cb_u32 ce = lds_word(C_CUM + (cs & 7));
-				if (g < ce) break;
-				cum0 = ce; ++cs;
-				base += TH; base = base >= RR ? base - RR : base;
-			}
-			if (!alive) break;
-			const int unit = (int)(g - cum0);
-			const cb_u32 *hdr = (const cb_u32 *)(TABl + (cs & 1) * TAB1 + NI);
-			const int nz = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[0]), NI));
-			const int nfast = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[1]), nz));
-			const int ngen = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[2]), nfast));
-			const int ntall = max(0, min(__builtin_amdgcn_readfirstlane((int)hdr[3]), nz));
-			const int nsplit = (A > 4 && ntall <= NSPLIT_MAX) ? ntall : 0;
-			const int usplit = (nsplit + 15) >> 4;
-			tile_unit<A, TW, SW, RR, PIPE>(unit, lane, Vl, Ml, UDl, OUTl + (cs & 1) * OUT1, TABl + (cs & 1) * TAB1, base, nz, nfast, ngen, nsplit, usplit);
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the unit's results are in the tile
-			if (lane == 0) atomicAdd(CT + C_DONE + (cs & 3), 1u);
-		}
-		return;
-	}
-
-	// ================= movers: mover mv owns rows mv HR .. mv HR + HR - 1 of every step (mover 0 also the item table) =================
-	const int mv = wvs - NCW;
-	__builtin_amdgcn_s_setprio(3);   // (few instructions, but every step waits for them)
-	constexpr int NV = (HR * UPR + 63) / 64, NM = (HR * MPR + 63) / 64, NU = (HR * UPRD + 63) / 64, NTB = (TABU + 63) / 64;
-	struct Rows { cb_u4 v[NV], m[NM], ud[NU], tab[NTB]; } R;
-	// requests this mover's rows of what step s adds to the ring (relative rows s TH + 2A + mv HR ..; s >= 2) and the step's table
-	auto fetch_step = [&](int s, int lane) {
-		const bool on = s < nsteps;
-		const int rr0 = s * TH + 2 * A + mv * HR;
-#pragma unroll
-		for (int k = 0; k < NV; ++k) {
-			const int q = lane + 64 * k, r = q / UPR, u = q - r * UPR;
-			R.v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, (on && r < HR) ? v_off(rr0 + r, u) : OOB, 0, VOL_AUX);
-		}
-#pragma unroll
-		for (int k = 0; k < NM; ++k) {
-			const int q = lane + 64 * k, r = q / MPR, u = q - r * MPR;
-			R.m[k] = __builtin_amdgcn_raw_buffer_load_b128(rpm, (on && r < HR) ? m_off(rr0 + r, u) : OOB, 0, 0);
-		}
-#pragma unroll
-		for (int k = 0; k < NU; ++k) {
-			const int q = lane + 64 * k, r = q / UPRD, u = q - r * UPRD;
-			R.ud[k] = __builtin_amdgcn_raw_buffer_load_b128(rpu, (on && r < HR) ? ud_off(rr0 + r, u) : OOB, 0, 0);
-		}
-#pragma unroll
-		for (int k = 0; k < NTB; ++k) {
-			const int q = lane + 64 * k;
-			R.tab[k] = __builtin_amdgcn_raw_buffer_load_b128(rplan, (on && mv == 0 && q < TABU) ? (cb_u32)(s * ENT + q * 16) : OOB, 0, 0);
-		}
-	};
-	// ... into the ring: slot0 = ring slot of relative row s TH + 2A (= the slot of step s - 2's first window row)
-	auto commit_step = [&](int s, int slot0, int lane) {
-		const int rr0 = s * TH + 2 * A + mv * HR;
-		auto slot_of = [&](int r) { int t = slot0 + mv * HR + r; return t >= RR ? t - RR : t; };
-#pragma unroll
-		for (int k = 0; k < NV; ++k) {
-			const int q = lane + 64 * k, r = q / UPR, u = q - r * UPR;
-			if (r < HR) *(cb_u4 *)(Vl + slot_of(r) * SW + 4 * u) = R.v[k];
-		}
-#pragma unroll
-		for (int k = 0; k < NM; ++k) {
-			const int q = lane + 64 * k, r = q / MPR, u = q - r * MPR;
-			if (r < HR) *(cb_u4 *)(Ml + slot_of(r) * TW + 8 * u) = row_in(rr0 + r) ? R.m[k] : cb_u4{0u, 0u, 0u, 0u};
-		}
-#pragma unroll
-		for (int k = 0; k < NU; ++k) {
-			const int q = lane + 64 * k, r = q / UPRD, u = q - r * UPRD;
-			if (r < HR) *(cb_u4 *)(UDl + slot_of(r) * TW + 16 * u) = row_in(rr0 + r) ? R.ud[k] : cb_u4{~0u, ~0u, ~0u, ~0u};
-		}
-		if (mv == 0) {
-#pragma unroll
-			for (int k = 0; k < NTB; ++k) {
-				const int q = lane + 64 * k;
-				if (q < TABU) *(cb_u4 *)(TABl + (s & 1) * TAB1 + 8 * q) = R.tab[k];
-			}
-		}
-	};
-	fetch_step(2, lane);
-	cb_u32 cum = lds_word(C_CUM + 1);   // (kept by both movers; the one that announces a step publishes it)
-	int slot0 = 0;                      // ring slot of step s's first window row
-	constexpr int OPR = TW / 4;         // 16-byte units of a tile row: 32, two rows per wave-wide read
-	for (int s = 0; s < nsteps; ++s) {
-		if (!wait_ge(C_DONE + (s & 3), lds_word(C_NUN + (s & 3)))) return;
-		int ln = lane;
-		asm volatile("" : "+v"(ln));   // (opaque: the per-lane index arithmetic of commit / requests is redone per step instead of living in registers)
-		// step s is complete.  This mover's rows of its tile -> registers (two rows per read: lanes 0-31 / 32-63)
-		cb_f4 ov[HR / 2];
-#pragma unroll
-		for (int k = 0; k < HR / 2; ++k) ov[k] = *(const cb_f4 *)(OUTl + (s & 1) * OUT1 + (mv * HR + 2 * k + (lane >> 5)) * TW + 4 * (lane & (OPR - 1)));
-		int nun = 0;
-		bool announced = false;
-		if (s + 2 < nsteps) {
-			commit_step(s + 2, slot0, ln);   // (waits for the rows requested a step ago) over step s's oldest TH rows, and the table
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (tile rows read, ring rows written)
-		}
-		// the movers meet: the last one to arrive announces the step (it sees the other's rows, and the table)
-		cb_u32 arrived = 0;
-		if (lane == 0) arrived = atomicAdd(CT + C_MOVERS, 1u);
-		arrived = (cb_u32)__builtin_amdgcn_readfirstlane((int)arrived);
-		if (s + 2 < nsteps && arrived == (cb_u32)(NMV * (s + 1) - 1)) {   // (the counter only grows: NMV arrivals per step, and no mover starts
-			asm volatile("" ::: "memory");                                  // step s + 1 before step s + 2 has been announced: see the end of the loop)
-			int oslot = slot0 + A;       // ring slot of step s + 2's first output row: relative row (s + 2) TH + A
-			oslot = oslot + 2 * TH >= RR ? oslot + 2 * TH - RR : oslot + 2 * TH;
-			copy_through(s + 2, oslot, 0, TH, lane, 64);   // (reads rows both movers have just committed)
-			const cb_u32 *h = (const cb_u32 *)(TABl + (s & 1) * TAB1 + NI);
-			nun = units_of(h[0], h[3]);
-			if (lane == 0) {
-				lds_set(C_DONE + (s & 3), 0u);
-				CT[C_NUN + ((s + 2) & 3)] = (cb_u32)nun;
-				CT[C_CUM + ((s + 2) & 7)] = cum + (cb_u32)nun;
-			}
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile columns and counts before the step is announced
-			if (lane == 0) lds_set(C_READY, (cb_u32)(s + 2));
-			announced = true;
-		}
-		// the tile's rows leave, then the rows of the step after next are requested
-#pragma unroll
-		for (int k = 0; k < HR / 2; ++k) {
-#pragma unroll
-			for (int hh = 0; hh < 2; ++hh) {   // a row per instruction (the other half wave is masked by its offset): the descriptor ends with
-				const int r = mv * HR + 2 * k + hh;   // the row, so that the words of a last unit beyond the image are dropped by the range check
-				const int y = ys + s * TH + r;
-				const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(P.vout + (size_t)d * HWi), 0, y < ye ? (y + 1) * W * 4 : 0, 0x00020000);
-				__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(ov[k].x), __float_as_uint(ov[k].y), __float_as_uint(ov[k].z), __float_as_uint(ov[k].w)}, rrow,
-				                                       (lane >> 5) == hh ? (cb_u32)(y * W + tx0 + 4 * (lane & (OPR - 1))) * 4u : OOB, 0, VOL_AUX);
-			}
-		}
-		if (s + 2 < nsteps) {   // both movers keep the cumulative count: the announcing one computed this step's units, the other waits for
-			if (!announced) {   // the announcement (so the movers are never a step apart) and reads them
-				if (!wait_ge(C_READY, (cb_u32)(s + 2))) return;
-				nun = (int)lds_word(C_NUN + ((s + 2) & 3));
-			}
-			cum += (cb_u32)nun;
-		}
-		fetch_step(s + 3, ln);
-		slot0 += TH; slot0 = slot0 >= RR ? slot0 - RR : slot0;
-	}
-}
-
 #ifdef MC_TILE_PROF
 extern "C" __attribute__((visibility("default"))) int mc_debug_tile_prof(unsigned long long *out, int n)
 {
@@ -1192,12 +877,6 @@ static void tile_regions(int H, int W, int TW, int TH, int &gx, int &gy, int &rb
 	gy = (int)cdiv(H, rb);
 }
 
-#ifndef MC_ROLL_DEFAULT_13
-#define MC_ROLL_DEFAULT_13 false   // (until measured)
-#endif
-#ifndef MC_ROLL_DEFAULT_4
-#define MC_ROLL_DEFAULT_4 false
-#endif
 // the product's geometries (128 x 16 tiles for either arm class) share one plan layout
 constexpr int PLAN_TW = 128, PLAN_TH = 16;
 // [header (PLAN_HDR) | item tables: D x regions x steps per region entries | combined runs (D, H, Wp) u16 | vertical arms (D, H, Wp) u8], Wp = W rounded up to whole tiles
@@ -1238,34 +917,8 @@ static int cbca_tiles_launch_mode(CbcaArgs P, bool nt, hipStream_t st)
 	return check_launch("cbca_tile");
 }
 
-// the plan-reading pass in its rolling form (cbca_roll_kernel): 8 compute waves + two movers, two blocks per CU
-template <int A, int TW, int TH>
-static int cbca_roll_launch(const CbcaArgs &P, bool nt, hipStream_t st)
-{
-	using G = TileGeo<A, TW, TH, 2>;
-	constexpr int NCW = 8, RR = 2 * TH + 2 * A;
-	constexpr int LDS = RR * G::SW * 4 + ((RR * TW * 2 + 15) & ~15) + ((RR * TW + 15) & ~15) + 2 * TH * TW * 4 + 2 * G::TAB_BYTES + 24 * 4;
-	static_assert(LDS <= 80 * 1024, "two blocks per CU");
-	const int64_t blocks = (int64_t)cdiv((int64_t)P.gx * P.gy, 8) * 8 * P.nd;
-	if (blocks > 0x7fffffff) {
-		set_error("cbca_roll: %lld blocks", (long long)blocks);
-		return MC_EINVAL;
-	}
-	auto kern_nt = cbca_roll_kernel<A, TW, TH, NCW, true>;
-	auto kern = cbca_roll_kernel<A, TW, TH, NCW, false>;
-	// (more than 64 KB of dynamic LDS: the attribute is per device and cheap to set -- on every launch, checked, as mean2d does)
-	const hipError_t e = hipFuncSetAttribute(nt ? (const void *)kern_nt : (const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-	if (e != hipSuccess) {
-		set_error("cbca_roll: hipFuncSetAttribute(%d bytes of LDS): %s", LDS, hipGetErrorString(e));
-		return (int)e;
-	}
-	if (nt) hipLaunchKernelGGL(kern_nt, dim3((unsigned)blocks), dim3(64 * (NCW + 2)), LDS, st, P);
-	else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * (NCW + 2)), LDS, st, P);
-	return check_launch("cbca_roll");
-}
-
 template <int A, int TW, int TH, int NWAVES>
-static int cbca_tiles_launch(CbcaArgs P, bool nt, int plan_mode, bool roll, hipStream_t st)
+static int cbca_tiles_launch(CbcaArgs P, bool nt, int plan_mode, hipStream_t st)
 {
 	tile_regions(P.H, P.W, TW, TH, P.gx, P.gy, P.rb);
 	P.spr = P.rb / TH;
@@ -1274,7 +927,6 @@ static int cbca_tiles_launch(CbcaArgs P, bool nt, int plan_mode, bool roll, hipS
 	if constexpr (TW == PLAN_TW && TH == PLAN_TH) {
 		static_assert(TileGeo<A, TW, TH>::ENT_BYTES == TileGeo<4, PLAN_TW, PLAN_TH>::ENT_BYTES, "one plan layout");
 		if (plan_mode == 1) return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 1>(P, nt, st);
-		if (plan_mode == 2 && roll) return cbca_roll_launch<A, TW, TH>(P, nt, st);
 		if (plan_mode == 2) return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 2>(P, nt, st);
 	}
 	return cbca_tiles_launch_mode<A, TW, TH, NWAVES, 0>(P, nt, st);   // (other geometries: no plan)
@@ -1299,21 +951,19 @@ int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, 
 	P.plan = pm ? cfg.plan : nullptr;
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
 	// cfg.variant selects the tile geometry (test / tuning hook; 0 = the product's choice)
-	// cfg.roll: the plan-reading pass in its rolling form (-1 = the product's choice per arm class, 0 / 1 forced)
-	const bool roll13 = cfg.roll < 0 ? MC_ROLL_DEFAULT_13 : cfg.roll != 0, roll4 = cfg.roll < 0 ? MC_ROLL_DEFAULT_4 : cfg.roll != 0;
 	if (arm_class <= 4) {
 		switch (cfg.variant) {
-		case 1: return cbca_tiles_launch<4, 128, 32, 8>(P, nt, pm, false, st);
-		case 2: return cbca_tiles_launch<4, 128, 32, 4>(P, nt, pm, false, st);
-		case 3: return cbca_tiles_launch<4, 256, 16, 8>(P, nt, pm, false, st);
-		default: return cbca_tiles_launch<4, 128, 16, 4>(P, nt, pm, roll4, st);
+		case 1: return cbca_tiles_launch<4, 128, 32, 8>(P, nt, pm, st);
+		case 2: return cbca_tiles_launch<4, 128, 32, 4>(P, nt, pm, st);
+		case 3: return cbca_tiles_launch<4, 256, 16, 8>(P, nt, pm, st);
+		default: return cbca_tiles_launch<4, 128, 16, 4>(P, nt, pm, st);
 		}
 	}
 	switch (cfg.variant) {
-	case 1: return cbca_tiles_launch<13, 128, 32, 8>(P, nt, pm, false, st);
-	case 2: return cbca_tiles_launch<13, 128, 16, 4>(P, nt, pm, false, st);
-	case 3: return cbca_tiles_launch<13, 64, 16, 4>(P, nt, pm, false, st);
-	default: return cbca_tiles_launch<13, 128, 16, 8>(P, nt, pm, roll13, st);
+	case 1: return cbca_tiles_launch<13, 128, 32, 8>(P, nt, pm, st);
+	case 2: return cbca_tiles_launch<13, 128, 16, 4>(P, nt, pm, st);
+	case 3: return cbca_tiles_launch<13, 64, 16, 4>(P, nt, pm, st);
+	default: return cbca_tiles_launch<13, 128, 16, 8>(P, nt, pm, st);
 	}
 }
 

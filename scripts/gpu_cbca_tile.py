@@ -27,8 +27,8 @@ for (H, W, D, L1, tau1), (name, mk) in cases:
     A.cbca_reference_shaped(x0c, x1c, vin, ref, -1)
     forms = ((0, "adcensus.cbca", 0), (1, "strip", 0), (2, "tile<4> v0", 0), (2, "tile<4> v1", 1), (2, "tile<4> v2", 2), (2, "tile<4> v3", 3)) if L1 <= 5 else (
         (0, "adcensus.cbca", 0), (1, "strip", 0), (3, "tile<13> v0", 0), (3, "tile<13> v1", 1), (3, "tile<13> v2", 2), (3, "tile<13> v3", 3))
-    forms = forms + (((4, "tile<4> sorts + writes the plan", 0), (6, "tile<4> reads the plan (barrier form)", 2), (6, "tile<4> reads the plan (rolling form)", 1)) if L1 <= 5 else
-                     ((5, "tile<13> sorts + writes the plan", 0), (7, "tile<13> reads the plan (barrier form)", 2), (7, "tile<13> reads the plan (rolling form)", 1)))
+    forms = forms + (((4, "tile<4> sorts + writes the plan", 0), (6, "tile<4> reads the plan", 0)) if L1 <= 5 else
+                     ((5, "tile<13> sorts + writes the plan", 0), (7, "tile<13> reads the plan", 0)))
     if "--plan-only" in sys.argv:
         forms = [f for f in forms if f[0] >= 4]
     if only_tile:

@@ -96,6 +96,31 @@ def test_tile_kernel_special_values(mc, oracle, form, L1):
         assert same_bits(got, want), diff_report(got, want, "tile kernel form %d, special values nt=%d" % (form, nt))
 
 
+def test_plan_of_another_problem_is_not_read(mc, oracle):
+    """forms 6 / 7 on a scratch whose plan was written for the other direction (or never): the pass stands down -- nothing is
+    written -- instead of walking a foreign plan (the plan's head says who wrote it)"""
+    H, W, D = 40, 150, 5
+    x0, x1 = blocky_pair(H, W, seed=2)
+    vl, vr = raw_volumes(D, H, W, seed=3)
+    for L1, forms in ((5, (4, 6)), (14, (5, 7))):
+        x0c, x1c = oracle.cross(x0, L1, 0.2), oracle.cross(x1, L1, 0.2)
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, form=forms[0])
+        assert same_bits(out.cpu().numpy(), oracle.cbca(x0c, x1c, vl, -1))
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vr), out, 1, form=forms[1])      # the plan on the scratch is direction -1's
+        assert (out.cpu().numpy() == -7.0).all()
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, form=forms[1])     # ... and is still direction -1's
+        assert same_bits(out.cpu().numpy(), oracle.cbca(x0c, x1c, vl, -1))
+    x0c, x1c = oracle.cross(x0, 5, 0.2), oracle.cross(x1, 5, 0.2)                  # arm class: a plan written by the long-arm instance
+    out = torch.full((1, D, H, W), -7.0, device="cuda")
+    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, form=5)
+    out = torch.full((1, D, H, W), -7.0, device="cuda")
+    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, form=6)
+    assert (out.cpu().numpy() == -7.0).all()
+
+
 def test_tile_kernel_stands_down_when_an_arm_is_too_long(mc, oracle):
     """the hook's forms 2 / 3 write nothing if cbca_pack saw an arm beyond the instance's class"""
     H, W, D = 40, 100, 3
@@ -129,15 +154,13 @@ def test_tile_kernel_with_plan(mc, oracle, H, W, D, mk, L1, tau1, forms):
         got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, vol, direction)
         assert same_bits(got, want), diff_report(got, want, "tile kernel writing the plan, dir=%d" % direction)
         for v in (vol2, vol):
-            for rb, what in ((2, "barrier form"), (1, "rolling form")):   # the plan-reading pass: a barrier per step / compute waves + mover
-                out = torch.full((1, D, H, W), -7.0, device="cuda")
-                mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(v), out, direction, nt=(H + W) & 1, rb=rb, form=forms[1])
-                got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, v, direction)
-                assert same_bits(got, want), diff_report(got, want, "tile kernel reading the plan (%s), dir=%d" % (what, direction))
+            out = torch.full((1, D, H, W), -7.0, device="cuda")
+            mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(v), out, direction, nt=(H + W) & 1, form=forms[1])
+            got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, v, direction)
+            assert same_bits(got, want), diff_report(got, want, "tile kernel reading the plan, dir=%d" % direction)
         if D >= 6:
-            for rb in (2, 1):
-                out = torch.full((1, D, H, W), -7.0, device="cuda")
-                mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol2), out, direction, d0=2, nd=3, rb=rb, form=forms[1])
-                got = out.cpu().numpy()[0]
-                want = oracle.cbca(x0c, x1c, vol2, direction)
-                assert same_bits(got[2:5], want[2:5]) and (got[:2] == -7.0).all() and (got[5:] == -7.0).all()
+            out = torch.full((1, D, H, W), -7.0, device="cuda")
+            mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol2), out, direction, d0=2, nd=3, form=forms[1])
+            got = out.cpu().numpy()[0]
+            want = oracle.cbca(x0c, x1c, vol2, direction)
+            assert same_bits(got[2:5], want[2:5]) and (got[:2] == -7.0).all() and (got[5:] == -7.0).all()
