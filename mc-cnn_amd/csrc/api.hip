@@ -651,15 +651,15 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 		// (forms 8 / 9 take the whole volume; nd > 0 = slots the list may hold, to exercise the fallback; d0: bits 0-1 rows in flight, bit 2 the listed outputs in a launch of their own)
 		cfg.plan = (char *)scratch + off;
 		cfg.plan_bytes = pb;
-		cfg.rb = rb;
-		cfg.variant = d0; cfg.d0 = 0; cfg.nd = nd;
+		cfg.lean_rb = rb;
+		cfg.lean_variant = d0; cfg.d0 = 0; cfg.nd = nd;
 		if (form == 8) {
 			rc = cbca_classify(scratch, cfg.plan, cfg.plan_bytes, D, H, W, direction, CR_NOT_DIRECT, rb, nd, st);
 			if (rc) return rc;
 		}
 		rc = cbca_lean(scratch, cfg.plan, cfg.plan_bytes, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT, st, cfg);
 		if (rc) return rc;
-		cfg.lean_rb = rb; cfg.rb = 0; cfg.variant = 0; cfg.nd = 0;
+		cfg.nd = 0;
 		rc = cbca_strips(scratch, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT_IF_NO_LIST, st, cfg);
 		if (rc) return rc;
 		return cbca_if_overflow(x0c, x1c, scratch, vol_in, vol_out, D, H, W, direction, st);

@@ -31,25 +31,59 @@ struct LeanArgs {
 	uint32_t cap;                // slots the list can hold
 	int D, H, W, direction;
 	int rb, gx, gy;              // rows per wave, strips per row, row chunks
+	cb_u32 gx_rcp;               // ceil(2^32 / gx)
+	int order, gyb;              // wave order: 0 linear over the volume, 1 one band of gyb row chunks per XCD (blockIdx & 7), each swept linearly
 	const uint32_t *flags;       // cbca_pack's flag words
 	int route;
 };
 
-__device__ __forceinline__ bool lean_list_valid(const LeanArgs &A) { return list_valid(A.hdr, A.D, A.H, A.W, A.direction, A.rb); }
+// does this launch run?  cbca_gate (the pair's route) and list_valid (the list is this problem's, and complete) with ONE wait: the
+// eight flag words and the eight header words are requested together (the short-lived waves of cbca_lean2_kernel cannot afford a
+// chain of dependent scalar loads before their rows are requested)
+__device__ __forceinline__ bool lean_runs(const LeanArgs &A)
+{
+	static_assert(CS_FLAGS == 8 && LH_RB < 8, "two 32-byte scalar loads");
+	const cb_u4 f0 = *(const cb_u4 *)A.flags, f1 = *(const cb_u4 *)(A.flags + 4);
+	const cb_u4 h0 = *(const cb_u4 *)A.hdr, h1 = *(const cb_u4 *)(A.hdr + 4);
+	(void)f1;
+	const cb_u32 fl[4] = {f0.x, f0.y, f0.z, f0.w};   // CF_SATURATED, CF_ARM_GT4, CF_ARM_GT13, CF_ROUTE
+	bool gate;
+	switch (A.route) {
+	case CR_ARMS_LE4: gate = !fl[CF_ARM_GT4]; break;
+	case CR_ARMS_LE13: gate = !fl[CF_ARM_GT13]; break;
+	case CR_NOT_DIRECT: gate = fl[CF_ROUTE] != CR_DIRECT; break;
+	case CR_STRIP_OR_TILE13: gate = fl[CF_ROUTE] == CR_STRIP || fl[CF_ROUTE] == CR_TILE13; break;
+	default: gate = fl[CF_ROUTE] == (cb_u32)A.route; break;
+	}
+	// (LH_COUNT, LH_OVERFLOW, LH_D, LH_H | LH_W, LH_DIR, LH_MAGIC, LH_RB)
+	const bool valid = (h1.z == LH_MAGIC_VALUE) & (h0.z == (cb_u32)A.D) & (h0.w == (cb_u32)A.H) & (h1.x == (cb_u32)A.W) &
+	                   (h1.y == (cb_u32)(A.direction + 1)) & (h1.w == (cb_u32)A.rb) & (h0.y == 0u);
+	return gate & valid;
+}
 
 // wave -> (plane, row chunk, strip of 256 columns); strips fastest, so that the waves of a block are neighbours in a row
-// (a strip's edge columns are its neighbours' lines: L1 / L2 hits)
+// (a strip's edge columns are its neighbours' lines: L1 / L2 hits).  w = the wave's number in the canonical order
+// (plane, chunk, strip): its word of the wave table.  order 1: the blocks of an XCD (blockIdx & 7: observed placement, used for
+// speed only) sweep ONE band of gyb row chunks of every plane, top to bottom, plane after plane -- so that each L2 streams a
+// contiguous range and holds the rows that vertically adjacent waves share.
+// (grid: x = the blocks of one plane, y = the plane -- planes are dispatched one after the other, no 64-bit division per wave)
 __device__ __forceinline__ bool lean_wave(const LeanArgs &A, int wv, long long &w, int &d, int &y0, int &y1, int &x0)
 {
-	w = (long long)blockIdx.x * 4 + wv;
-	const int strip = (int)(w % A.gx);
-	const long long t = w / A.gx;
-	const int chunk = (int)(t % A.gy);
-	d = (int)(t / A.gy);
+	d = (int)blockIdx.y;
+	const cb_u32 lw = (A.order == 1 ? (blockIdx.x >> 3) : blockIdx.x) * 4u + (cb_u32)wv;
+	const cb_u32 t = __umulhi(lw, A.gx_rcp);   // lw / gx (exact for lw < 2^16: gx_rcp = ceil(2^32 / gx))
+	const int strip = (int)(lw - t * (cb_u32)A.gx);
+	int chunk = (int)t;
+	if (A.order == 1) {
+		if (chunk >= A.gyb) return false;
+		chunk += (int)(blockIdx.x & 7) * A.gyb;
+	}
+	if (chunk >= A.gy) return false;
+	w = ((long long)d * A.gy + chunk) * A.gx + strip;
 	y0 = chunk * A.rb;
 	y1 = min(A.H, y0 + A.rb);
 	x0 = strip * 256;
-	return d < A.D;
+	return true;
 }
 
 // byte j (0 .. 11) of the entry's words 1 .. 3
@@ -259,7 +293,7 @@ __global__ void __launch_bounds__(256) cbca_lean_kernel(const LeanArgs A)
 {
 	static_assert(PF % 3 == 0, "the neighbour columns of the three-row window rotate by renaming");
 	constexpr int AUX = NT ? 2 : 0;   // volumes far beyond the 256 MB Infinity Cache are streamed (cbca_strip_kernel)
-	if (!cbca_gate(A.flags, A.route) || !lean_list_valid(A)) return;
+	if (!lean_runs(A)) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	long long w;
@@ -341,10 +375,83 @@ __global__ void __launch_bounds__(256) cbca_lean_kernel(const LeanArgs A)
 	}
 }
 
+// ---- the same pass as short-lived waves --------------------------------------------------------------------------------------
+// What a plain copy reaches on this chip depends on how the waves in flight lie in memory: 5.0 - 5.5 TB/s at 2 x 2 GB for a
+// grid-stride copy of 16 K blocks, 6.3 / 6.7 TB/s (plain / non-temporal) for ONE 16-byte element per thread, dispatched in address
+// order (profiles/r04_bw_sizes.txt).  The kernel above is of the first kind (6 K waves, each walking 125 rows of a region of its
+// own); this one is of the second: a wave owns R output rows x 256 columns, requests its R + 2 rows at once, computes, stores and
+// ends -- hundreds of thousands of waves dispatched in address order (or, order 1, in address order inside one band of rows per
+// XCD, so that the two rows a wave shares with each vertical neighbour come out of that XCD's L2).  The wave's listed outputs
+// follow at once: their rows are the ones it and its neighbours have just read.
+template <int R, bool NT, bool INLINE_LIST>
+__global__ void __launch_bounds__(256) cbca_lean2_kernel(const LeanArgs A)
+{
+	constexpr int AUX = NT ? 2 : 0;
+	if (!lean_runs(A)) return;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	long long w;
+	int d, y0, y1, xb;
+	if (!lean_wave(A, wv, w, d, y0, y1, xb)) return;
+	const int H = A.H, W = A.W;
+	const int HWi = H * W;
+	const int sh = d * A.direction;
+	const int xs = xb + 4 * lane;
+	const cb_u32 OOB = 0x80000000u;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
+	const bool lane_in = xs < W;
+	const int ecol = lane == 0 ? xs - 1 : (lane == 63 ? xs + 4 : -1);
+	const bool eok = ecol >= 0 && ecol < W;
+	cb_u32 inr = 0;   // bit j: the output has a partner (adcensus.cu:353)
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+		if (xs + j + sh >= 0 && xs + j + sh < W) inr |= 1u << j;
+	// rows y0 - 1 .. y0 + R, all requested before the first is used (loads as in cbca_lean_kernel: no branch, rows outside the image: zeros)
+	cb_u4 v[R + 2];
+	cb_u32 e[R + 2];
+#pragma unroll
+	for (int k = 0; k < R + 2; ++k) {
+		const int r = y0 - 1 + k;
+		const bool rok = (unsigned)r < (unsigned)H;
+		v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, (rok & lane_in) ? (cb_u32)(r * W + xs) * 4u : OOB, 0, AUX);
+		e[k] = __builtin_amdgcn_raw_buffer_load_b32(rv, (rok & eok) ? (cb_u32)(r * W + ecol) * 4u : OOB, 0, 0);
+	}
+	float row[R + 2][6];   // columns xs - 1 .. xs + 4
+#pragma unroll
+	for (int k = 0; k < R + 2; ++k) {
+		row[k][1] = __uint_as_float(v[k].x); row[k][2] = __uint_as_float(v[k].y); row[k][3] = __uint_as_float(v[k].z); row[k][4] = __uint_as_float(v[k].w);
+		row[k][0] = lane_from_below(row[k][4], __uint_as_float(e[k]));   // lane 0: the strip's left outer column
+		row[k][5] = lane_from_above(row[k][1], __uint_as_float(e[k]));   // lane 63: its right outer column
+	}
+#pragma unroll
+	for (int k = 0; k < R; ++k) {
+		const int yo = y0 + k;
+		float res[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			float sum = 0;
+			sum += row[k][j]; sum += row[k][j + 1]; sum += row[k][j + 2];
+			sum += row[k + 1][j]; sum += row[k + 1][j + 1]; sum += row[k + 1][j + 2];
+			sum += row[k + 2][j]; sum += row[k + 2][j + 1]; sum += row[k + 2][j + 2];
+			float q = sum / 9.0f;
+			asm volatile("" : "+v"(q));
+			res[j] = ((inr >> j) & 1u) ? q : row[k + 1][j + 1];
+		}
+		const bool myrow = yo < y1;
+		const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, myrow ? (yo + 1) * W * 4 : 0, 0x00020000);
+		__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
+		                                       rrow, (myrow & lane_in) ? (cb_u32)(yo * W + xs) * 4u : OOB, 0, AUX);
+	}
+	if (INLINE_LIST) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the same addresses are written again, by other lanes)
+		list_phase(A, w, d, lane);
+	}
+}
+
 // ... the listed outputs in a launch of their own (one wave per wave of the lean kernel): the form the inline one is measured against
 __global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
 {
-	if (!cbca_gate(A.flags, A.route) || !lean_list_valid(A)) return;
+	if (!lean_runs(A)) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	long long w;
@@ -354,8 +461,17 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
 }
 
 
+// rows per wave / launch variant mc_predict uses (cfg.lean_rb = 0 / cfg.lean_variant < 0)
+#ifndef MC_LEAN_RB_DEFAULT
+#define MC_LEAN_RB_DEFAULT 0        // 0: cbca_lean_kernel with rows per wave by size; 2 / 4 / 8: cbca_lean2_kernel
+#endif
+#ifndef MC_LEAN_VARIANT_DEFAULT
+#define MC_LEAN_VARIANT_DEFAULT 0
+#endif
+int cbca_lean_default_rows() { return MC_LEAN_RB_DEFAULT; }
+
 static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
-                          int route, int rb, int cap_limit = 0)
+                          int route, int rb, int cap_limit = 0, int order = 0)
 {
 	LeanArgs A;
 	const CbcaScratch cs = cbca_scratch(packed, H, W);
@@ -368,6 +484,9 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	const int64_t gy_min = cdiv((int64_t)12288, (int64_t)A.gx * D);
 	A.rb = rb > 0 ? rb : (int)std::min<int64_t>(128, std::max<int64_t>(16, cdiv((int64_t)H, gy_min)));
 	A.gy = (int)cdiv(H, A.rb);
+	A.order = order;
+	A.gyb = (int)cdiv(A.gy, 8);
+	A.gx_rcp = (cb_u32)((((uint64_t)1 << 32) + A.gx - 1) / A.gx);
 	const int64_t waves = (int64_t)A.gx * A.gy * D;
 	A.wtab_words = LH_WORDS;
 	A.slots_words = (uint32_t)((LH_WORDS + 2 * waves + 3) / 4 * 4);
@@ -382,58 +501,73 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 // rows per wave of the lean / classify kernels for a problem (rb > 0: forced): the list is valid for this value only
 int cbca_lean_rows(int D, int H, int W, int rb)
 {
-	return lean_args(nullptr, nullptr, 0, nullptr, nullptr, D, H, W, -1, 0, rb).rb;
+	return lean_args(nullptr, nullptr, 0, nullptr, nullptr, D, H, W, -1, 0, rb > 0 ? rb : MC_LEAN_RB_DEFAULT).rb;
+}
+
+// blocks of 4 waves: x over one plane's (chunk, strip) pairs -- order 1: eight bands of gyb chunks, band = blockIdx.x & 7 --, y = plane
+static dim3 lean_grid(const LeanArgs &A)
+{
+	const unsigned per_plane = A.order == 1 ? 8u * cdiv((int64_t)A.gx * A.gyb, 4) : cdiv((int64_t)A.gx * A.gy, 4);
+	return dim3(per_plane, (unsigned)A.D);
 }
 
 bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes)
 {
-	if ((int64_t)D * H * W >= ((int64_t)1 << 32)) return false;   // (32-bit voxel indices in the entries)
+	if ((int64_t)D * H * W >= ((int64_t)1 << 32) || D > 65535) return false;   // (32-bit voxel indices in the entries; the plane is blockIdx.y)
 	const LeanArgs A = lean_args(nullptr, nullptr, plan_bytes, nullptr, nullptr, D, H, W, -1, 0, 0);
-	return A.cap >= 2 && (int64_t)A.gx * A.gy * D < ((int64_t)1 << 30);
+	return A.cap >= 2 && (int64_t)A.gx * A.gy < 65536 && (int64_t)A.gx * A.gy * D < ((int64_t)1 << 30);
 }
 
 // once per pair and direction (before the first pass): the list of outputs whose support is not the minimal 3 x 3
 int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, int rb, int cap_limit,
                   hipStream_t st)
 {
-	const LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb, cap_limit);
+	const LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb > 0 ? rb : MC_LEAN_RB_DEFAULT, cap_limit);
 	const hipError_t e = hipMemsetAsync(plan, 0, (size_t)A.slots_words * 4, st);   // header + wave table
 	if (e != hipSuccess) {
 		set_error("cbca_classify: %s", hipGetErrorString(e));
 		return (int)e;
 	}
-	const int64_t waves = (int64_t)A.gx * A.gy * D;
-	hipLaunchKernelGGL(cbca_classify_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, st, A);
+	hipLaunchKernelGGL(cbca_classify_kernel, lean_grid(A), dim3(256), 0, st, A);
 	return check_launch("cbca_classify");
 }
 
-// one aggregation pass: the lean kernel over every output + the listed outputs (cfg.variant: bits 0-1 rows in flight 6 / 3 / 9 / 12,
-// bit 2 the listed outputs in a launch of their own)
+// one aggregation pass: the lean kernel over every output + the listed outputs.  cfg.lean_rb: rows per wave (0 = by size);
+// cfg.lean_variant: bits 0-1 rows in flight 6 / 3 / 9 / 12 (cbca_lean_kernel), bit 2 the listed outputs in a launch of their own,
+// bit 3 cbca_lean2_kernel (short-lived waves of lean_rb = 2 / 4 / 8 rows), bit 4 one band of rows per XCD
 int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
               int route, hipStream_t st, const CbcaCfg &cfg)
 {
-	const LeanArgs A = lean_args(packed, (void *)plan, plan_bytes, vin, vout, D, H, W, direction, route, cfg.rb, cfg.nd);
-	const int64_t waves = (int64_t)A.gx * A.gy * D;
+	const int variant = cfg.lean_variant >= 0 ? cfg.lean_variant : (MC_LEAN_VARIANT_DEFAULT | (MC_LEAN_RB_DEFAULT ? 8 : 0));
+	const bool v2 = (variant & 8) != 0;
+	const int order = (variant & 16) ? 1 : 0;
+	int rb = cfg.lean_rb > 0 ? cfg.lean_rb : MC_LEAN_RB_DEFAULT;
+	if (v2 && rb != 2 && rb != 4 && rb != 8) rb = 4;
+	const LeanArgs A = lean_args(packed, (void *)plan, plan_bytes, vin, vout, D, H, W, direction, route, rb, cfg.nd, order);
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)D * H * W * 4 > ((int64_t)768 << 20);
-	const unsigned blocks = (unsigned)cdiv(waves, 4);
-	const bool own_launch = (cfg.variant & 4) != 0;
-	const int pf = cfg.variant & 3;
-#define MC_LEAN_LAUNCH(PF) do { \
+	const dim3 blocks = lean_grid(A);
+	const bool own_launch = (variant & 4) != 0;
+	const int pf = variant & 3;
+#define MC_LEAN_GO(KERNEL, P) do { \
 		if (own_launch) { \
-			if (nt) hipLaunchKernelGGL((cbca_lean_kernel<PF, true, false>), dim3(blocks), dim3(256), 0, st, A); \
-			else hipLaunchKernelGGL((cbca_lean_kernel<PF, false, false>), dim3(blocks), dim3(256), 0, st, A); \
+			if (nt) hipLaunchKernelGGL((KERNEL<P, true, false>), blocks, dim3(256), 0, st, A); \
+			else hipLaunchKernelGGL((KERNEL<P, false, false>), blocks, dim3(256), 0, st, A); \
 		} else { \
-			if (nt) hipLaunchKernelGGL((cbca_lean_kernel<PF, true, true>), dim3(blocks), dim3(256), 0, st, A); \
-			else hipLaunchKernelGGL((cbca_lean_kernel<PF, false, true>), dim3(blocks), dim3(256), 0, st, A); \
+			if (nt) hipLaunchKernelGGL((KERNEL<P, true, true>), blocks, dim3(256), 0, st, A); \
+			else hipLaunchKernelGGL((KERNEL<P, false, true>), blocks, dim3(256), 0, st, A); \
 		} } while (0)
-	if (pf == 1) MC_LEAN_LAUNCH(3);
-	else if (pf == 2) MC_LEAN_LAUNCH(9);
-	else if (pf == 3) MC_LEAN_LAUNCH(12);
-	else MC_LEAN_LAUNCH(6);
-#undef MC_LEAN_LAUNCH
+	if (v2) {
+		if (rb == 2) MC_LEAN_GO(cbca_lean2_kernel, 2);
+		else if (rb == 8) MC_LEAN_GO(cbca_lean2_kernel, 8);
+		else MC_LEAN_GO(cbca_lean2_kernel, 4);
+	} else if (pf == 1) MC_LEAN_GO(cbca_lean_kernel, 3);
+	else if (pf == 2) MC_LEAN_GO(cbca_lean_kernel, 9);
+	else if (pf == 3) MC_LEAN_GO(cbca_lean_kernel, 12);
+	else MC_LEAN_GO(cbca_lean_kernel, 6);
+#undef MC_LEAN_GO
 	int rc = check_launch("cbca_lean");
 	if (rc || !own_launch) return rc;
-	hipLaunchKernelGGL(cbca_list_kernel, dim3(blocks), dim3(256), 0, st, A);
+	hipLaunchKernelGGL(cbca_list_kernel, blocks, dim3(256), 0, st, A);
 	return check_launch("cbca_list");
 }
 

@@ -34,7 +34,8 @@ struct CbcaCfg {
 	void *plan = nullptr;   // tile kernel: cbca_plan_bytes() bytes holding the item order of this pair and direction, or null
 	int plan_mode = 0; // 0 = no plan (every launch sorts its items), 1 = this launch sorts and writes the plan, 2 = this launch reads it
 	size_t plan_bytes = 0;  // size of *plan
-	int lean_rb = 0;   // ... rows per wave of the lean kernels that wrote / read the list (0 = auto)
+	int lean_rb = 0;   // ... rows per wave of the lean kernels that wrote / read the list (0 = the product's choice)
+	int lean_variant = -1;  // ... launch variant of the lean kernels (-1 = the product's choice; cbca_lean.hip)
 	bool lean = false; // route CR_STRIP is served by the lean + list kernels (cbca_lean.hip) out of the list cbca_classify wrote to *plan
 };
 

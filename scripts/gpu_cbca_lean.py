@@ -34,6 +34,8 @@ def run(tag, **kw):
 run("strip kernel", form=1)
 # (a pass that reads the list must use the rows per wave the list was written for: every variant lists first -- form 8 -- the kernels'
 # own times are in the rocprofv3 trace, per kernel name and grid size)
-for variant, tag in ((0, "PF=6 inline"), (4, "PF=6, listed outputs in their own launch"), (2, "PF=9 inline"), (3, "PF=12 inline"), (6, "PF=9 own"), (7, "PF=12 own")):
-    for rb in (0, 250, 500, 1000):
-        run("classify + lean<%s> rb=%d" % (tag, rb), form=8, rb=rb, d0=variant)
+run("classify + lean<PF=6 inline> rb=auto", form=8, rb=0, d0=0)
+run("classify + lean<PF=6 own list launch> rb=auto", form=8, rb=0, d0=4)
+for rb in (2, 4, 8):
+    for variant, tag in ((8, "linear order"), (24, "a band per XCD"), (12, "linear, own list launch"), (28, "band per XCD, own list launch")):
+        run("classify + lean2<R=%d, %s>" % (rb, tag), form=8, rb=rb, d0=variant)

@@ -61,5 +61,31 @@ int main()
 		}
 		printf("%10zu %14.2f %14.2f %14.2f %14.2f\n", mb, res[0], res[1], res[2], res[3]);
 	}
+	// round 4: is the guide's 6.29 TB/s float4 copy reachable at the working set of this pipeline's volumes (2 x 1.5 ... 2 GB,
+	// touched once per kernel)?  Grid sizes from one block per CU to one thread per element, both cache policies, at S = 1.5 GB and 2 GB.
+	printf("\n%10s %10s %14s %14s\n", "S (MB)", "blocks", "copy TB/s", "copy nt TB/s");
+	for (size_t mb : {1536, 2048}) {
+		const size_t bytes = mb << 20, n = bytes / 16;
+		for (long blocks : {256L, 512L, 1024L, 2048L, 4096L, 8192L, 16384L, 65536L, (long)((n + 255) / 256)}) {
+			double res[2];
+			for (int mode = 0; mode < 2; ++mode) {
+				auto go = [&](int i) {
+					const f4v *src = (i & 1) ? b : a;
+					f4v *dst = (i & 1) ? a : b;
+					if (mode == 0) hipLaunchKernelGGL((copyk<0>), dim3((unsigned)blocks), dim3(256), 0, 0, src, dst, n);
+					else hipLaunchKernelGGL((copyk<1>), dim3((unsigned)blocks), dim3(256), 0, 0, src, dst, n);
+				};
+				for (int i = 0; i < 2; ++i) go(i);
+				CK(hipDeviceSynchronize());
+				CK(hipEventRecord(e0));
+				for (int i = 0; i < 10; ++i) go(i);
+				CK(hipEventRecord(e1));
+				CK(hipEventSynchronize(e1));
+				float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+				res[mode] = 2.0 * bytes / 1e12 / (ms / 10 * 1e-3);
+			}
+			printf("%10zu %10ld %14.2f %14.2f\n", mb, blocks, res[0], res[1]);
+		}
+	}
 	return 0;
 }

@@ -61,6 +61,28 @@ def test_lean_rows_per_wave_and_prefetch_depth(mc, oracle, rb, variant):
         assert same_bits(got, want), diff_report(got, want, "rb=%d variant=%d dir=%d" % (rb, variant, direction))
 
 
+@pytest.mark.parametrize("H,W,D", [(61, 530, 5), (90, 300, 9), (5, 7, 3), (17, 257, 9), (3, 1030, 5), (140, 130, 3), (1, 9, 2)])
+@pytest.mark.parametrize("rb", [2, 4, 8])
+@pytest.mark.parametrize("variant", [8, 24, 12, 28])   # bit 3: short-lived waves of rb rows, bit 4: one band of rows per XCD, bit 2: own list launch
+@pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.05), ("blocky", 14, 0.2)])
+def test_lean_short_lived_waves(mc, oracle, H, W, D, rb, variant, mk, L1, tau1):
+    """cbca_lean2_kernel: a wave per rb output rows x 256 columns, dispatched in address order / per-XCD bands; images smaller than
+    eight bands, ragged widths, both directions, a second volume out of the same list"""
+    x0, x1 = pair(mk, H, W, D)
+    x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
+    vl, vr = raw_volumes(D, H, W, seed=5)
+    v2l, v2r = raw_volumes(D, H, W, seed=6)
+    for direction, vol, vol2 in ((-1, vl, v2l), (1, vr, v2r)):
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol), out, direction, rb=rb, d0=variant, nt=H & 1, form=8)
+        got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, vol, direction)
+        assert same_bits(got, want), diff_report(got, want, "rb=%d variant=%d dir=%d" % (rb, variant, direction))
+        out = torch.full((1, D, H, W), -7.0, device="cuda")
+        mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol2), out, direction, rb=rb, d0=variant, form=9)
+        got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, vol2, direction)
+        assert same_bits(got, want), diff_report(got, want, "reading the list: rb=%d variant=%d dir=%d" % (rb, variant, direction))
+
+
 def test_lean_special_values(mc, oracle):
     """zeros, negative zeros, denormals, huge values, infinities and NaNs inside the valid region: the lean kernel's window reads
     every neighbour, but a value outside an output's support is an operand only of outputs that are listed and recomputed; a
