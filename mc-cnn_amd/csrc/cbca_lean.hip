@@ -26,7 +26,9 @@ struct LeanArgs {
 	const float *vin;
 	float *vout;
 	uint32_t *hdr;               // list header (LH_*); behind it the wave table and the slots
-	uint32_t wtab_words;         // word offset of the wave table: per wave of the lean kernel {first segment's slot + 1, 0}
+	uint32_t cnt_words;          // word offset of the per-plane slot counters (the slots are allotted per plane: capd each)
+	uint32_t capd;               // slots per plane
+	uint32_t wtab_words;         // word offset of the wave table: per wave of the lean kernel {first segment's slot + 1, its entries | more segments << 31}
 	uint32_t slots_words;        // word offset of the slots (16 bytes each)
 	uint32_t cap;                // slots the list can hold
 	int D, H, W, direction;
@@ -71,7 +73,7 @@ __device__ __forceinline__ bool lean_wave(const LeanArgs &A, int wv, long long &
 {
 	d = (int)blockIdx.y;
 	const cb_u32 lw = (A.order == 1 ? (blockIdx.x >> 3) : blockIdx.x) * 4u + (cb_u32)wv;
-	const cb_u32 t = __umulhi(lw, A.gx_rcp);   // lw / gx (exact for lw < 2^16: gx_rcp = ceil(2^32 / gx))
+	const cb_u32 t = A.gx == 1 ? lw : __umulhi(lw, A.gx_rcp);   // lw / gx (exact for lw < 2^16: gx_rcp = ceil(2^32 / gx), gx >= 2)
 	const int strip = (int)(lw - t * (cb_u32)A.gx);
 	int chunk = (int)t;
 	if (A.order == 1) {
@@ -100,11 +102,65 @@ __device__ __forceinline__ cb_u32 entry_byte(const cb_u4 &e, int j)
 //   byte 0 = up | down << 4 (< 0xe0)    at most 11 rows, arms up to 13 / 15: bytes 1 .. 11 = left | right << 4 per row
 //   byte 0 = 0xff                       anything else: the arm lengths are looked up
 // Runs are read four values at a time (any 4-byte alignment); the values behind a run's end add -0.0f (x + -0.0f == x).
-__device__ __forceinline__ void list_phase(const LeanArgs &A, long long w, int d, int lane)
+// value of one listed output (entry e of plane d; rem = y * W + x): the reference's loop out of the entry's shape
+__device__ __forceinline__ float list_entry_value(const LeanArgs &A, const __amdgpu_buffer_rsrc_t &rv, int d, const cb_u4 &e, cb_u32 rem)
 {
-	const int W = A.W, HWi = A.H * A.W;
+	const int W = A.W;
 	const int sh = d * A.direction;
 	const cb_u32 OOB = 0x80000000u;
+	const cb_u32 b0 = e.y & 0xffu;
+	float sum = 0;
+	int cnt = 0;
+	if ((b0 & 0xf0u) == 0xe0u) {
+		const int u = (int)(b0 & 3u), rows = u + (int)((b0 >> 2) & 3u) + 1;
+		cb_u4 v[4];
+		int nn[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const cb_u32 lr = entry_byte(e, 1 + k);
+			nn[k] = k < rows ? (int)(lr & 15u) + (int)(lr >> 4) + 1 : 0;
+			v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, k < rows ? (cb_u32)((int)rem + (k - u) * W - (int)(lr & 15u)) * 4u : OOB, 0, 0);
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			sum += 0 < nn[k] ? __uint_as_float(v[k].x) : -0.0f;
+			sum += 1 < nn[k] ? __uint_as_float(v[k].y) : -0.0f;
+			sum += 2 < nn[k] ? __uint_as_float(v[k].z) : -0.0f;
+			sum += 3 < nn[k] ? __uint_as_float(v[k].w) : -0.0f;
+			cnt += nn[k];
+		}
+	} else if (b0 != 0xffu) {
+		const int u = (int)(b0 & 15u), rows = u + (int)(b0 >> 4) + 1;
+		for (int k = 0; k < rows; ++k) {
+			const cb_u32 lr = entry_byte(e, 1 + k);
+			const int l = (int)(lr & 15u), nk = l + (int)(lr >> 4) + 1;
+			const int start = (int)rem + (k - u) * W - l;
+			for (int c = 0; c < nk; c += 4) {
+				const cb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rv, (cb_u32)(start + c) * 4u, 0, 0);
+				sum += __uint_as_float(v.x);
+				sum += c + 1 < nk ? __uint_as_float(v.y) : -0.0f;
+				sum += c + 2 < nk ? __uint_as_float(v.z) : -0.0f;
+				sum += c + 3 < nk ? __uint_as_float(v.w) : -0.0f;
+			}
+			cnt += nk;
+		}
+	} else {
+		const uint32_t mm = bytemin4(A.p0[rem], A.p1[(int)rem + sh]);
+		const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
+		for (int q = -u; q <= dn; ++q) {
+			const int g = (int)rem + q * W;
+			const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
+			const int l = (int)(m & 0xffu), nk = l + (int)((m >> 8) & 0xffu) + 1;
+			for (int k = 0; k < nk; ++k) sum += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, (cb_u32)(g - l + k) * 4u, 0, 0));
+			cnt += nk;
+		}
+	}
+	return sum / (float)cnt;
+}
+
+__device__ __forceinline__ void list_phase(const LeanArgs &A, long long w, int d, int lane)
+{
+	const int HWi = A.H * A.W;
 	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
 	const uint32_t *__restrict__ slots = A.hdr + A.slots_words;
 	cb_u32 seg = A.hdr[A.wtab_words + 2 * w];   // slot + 1 of the wave's first segment
@@ -118,54 +174,7 @@ __device__ __forceinline__ void list_phase(const LeanArgs &A, long long w, int d
 			const cb_u4 e = *(const cb_u4 *)(slots + (size_t)(seg + i) * 4);
 			const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;   // y * W + x
 			if (rem >= (cb_u32)HWi) continue;   // (not this plane's: never written by cbca_classify_kernel)
-			const cb_u32 b0 = e.y & 0xffu;
-			float sum = 0;
-			int cnt = 0;
-			if ((b0 & 0xf0u) == 0xe0u) {
-				const int u = (int)(b0 & 3u), rows = u + (int)((b0 >> 2) & 3u) + 1;
-				cb_u4 v[4];
-				int nn[4];
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					const cb_u32 lr = entry_byte(e, 1 + k);
-					nn[k] = k < rows ? (int)(lr & 15u) + (int)(lr >> 4) + 1 : 0;
-					v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, k < rows ? (cb_u32)((int)rem + (k - u) * W - (int)(lr & 15u)) * 4u : OOB, 0, 0);
-				}
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					sum += 0 < nn[k] ? __uint_as_float(v[k].x) : -0.0f;
-					sum += 1 < nn[k] ? __uint_as_float(v[k].y) : -0.0f;
-					sum += 2 < nn[k] ? __uint_as_float(v[k].z) : -0.0f;
-					sum += 3 < nn[k] ? __uint_as_float(v[k].w) : -0.0f;
-					cnt += nn[k];
-				}
-			} else if (b0 != 0xffu) {
-				const int u = (int)(b0 & 15u), rows = u + (int)(b0 >> 4) + 1;
-				for (int k = 0; k < rows; ++k) {
-					const cb_u32 lr = entry_byte(e, 1 + k);
-					const int l = (int)(lr & 15u), nk = l + (int)(lr >> 4) + 1;
-					const int start = (int)rem + (k - u) * W - l;
-					for (int c = 0; c < nk; c += 4) {
-						const cb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rv, (cb_u32)(start + c) * 4u, 0, 0);
-						sum += __uint_as_float(v.x);
-						sum += c + 1 < nk ? __uint_as_float(v.y) : -0.0f;
-						sum += c + 2 < nk ? __uint_as_float(v.z) : -0.0f;
-						sum += c + 3 < nk ? __uint_as_float(v.w) : -0.0f;
-					}
-					cnt += nk;
-				}
-			} else {
-				const uint32_t mm = bytemin4(A.p0[rem], A.p1[(int)rem + sh]);
-				const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
-				for (int q = -u; q <= dn; ++q) {
-					const int g = (int)rem + q * W;
-					const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
-					const int l = (int)(m & 0xffu), nk = l + (int)((m >> 8) & 0xffu) + 1;
-					for (int k = 0; k < nk; ++k) sum += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, (cb_u32)(g - l + k) * 4u, 0, 0));
-					cnt += nk;
-				}
-			}
-			A.vout[(size_t)d * HWi + rem] = sum / (float)cnt;
+			A.vout[(size_t)d * HWi + rem] = list_entry_value(A, rv, d, e, rem);
 		}
 		seg = next;
 	}
@@ -218,19 +227,28 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 	uint32_t *__restrict__ slots = A.hdr + A.slots_words;
 	int cnt = 0;
 	cb_u32 prev = 0;   // slot + 1 of this wave's last segment header
+	cb_u32 first_cnt = 0;
 	auto flush = [&]() {
-		cb_u32 base = 0;
-		if (lane == 0) base = atomicAdd(A.hdr + LH_COUNT, (cb_u32)cnt + 1u);
-		base = (cb_u32)__builtin_amdgcn_readfirstlane((int)base);
-		if (base + (cb_u32)cnt + 1u > A.cap) {   // the list does not fit: the passes fall back to the strip kernel
+		// slots are allotted per plane (one counter per plane: a single counter for 400 K waves is four milliseconds of atomics)
+		cb_u32 local = 0;
+		if (lane == 0) local = atomicAdd(A.hdr + A.cnt_words + d, (cb_u32)cnt + 1u);
+		local = (cb_u32)__builtin_amdgcn_readfirstlane((int)local);
+		if (local + (cb_u32)cnt + 1u > A.capd) {   // the list does not fit: the passes fall back to the strip kernel
 			if (lane == 0) A.hdr[LH_OVERFLOW] = 1u;
 			cnt = 0;
 			return;
 		}
+		const cb_u32 base = (cb_u32)d * A.capd + local;
 		if (lane == 0) {
 			*(cb_u4 *)(slots + (size_t)base * 4) = cb_u4{(cb_u32)cnt, 0u, 0u, 0u};
-			if (prev) slots[(size_t)(prev - 1) * 4 + 1] = base + 1u;
-			else A.hdr[A.wtab_words + 2 * w] = base + 1u;
+			if (prev) {
+				slots[(size_t)(prev - 1) * 4 + 1] = base + 1u;
+				A.hdr[A.wtab_words + 2 * w + 1] = first_cnt | 0x80000000u;   // more than one segment
+			} else {
+				A.hdr[A.wtab_words + 2 * w] = base + 1u;
+				A.hdr[A.wtab_words + 2 * w + 1] = (cb_u32)cnt;
+				first_cnt = (cb_u32)cnt;
+			}
 		}
 		prev = base + 1u;
 		for (int i = lane; i < cnt; i += 64) {
@@ -383,10 +401,23 @@ __global__ void __launch_bounds__(256) cbca_lean_kernel(const LeanArgs A)
 // ends -- hundreds of thousands of waves dispatched in address order (or, order 1, in address order inside one band of rows per
 // XCD, so that the two rows a wave shares with each vertical neighbour come out of that XCD's L2).  The wave's listed outputs
 // follow at once: their rows are the ones it and its neighbours have just read.
-template <int R, bool NT, bool INLINE_LIST>
+// s / 9 in three operations: q = s r, e = fma(-9, q, s), q' = fma(e, r, q) with r = RN(1 / 9) -- equal to the IEEE quotient for EVERY
+// float with 2^-95 <= |s| < 2^125 (tests/test_div9.py walks all 2^32 bit patterns); outside that range the IEEE divide.
+__device__ __forceinline__ float div9(float s)
+{
+	const float r = 0x1.c71c72p-4f;
+	const float q = s * r;
+	const float e = __builtin_fmaf(-9.0f, q, s);
+	return __builtin_fmaf(e, r, q);
+}
+__device__ __forceinline__ bool div9_ok(float s) { const float a = __builtin_fabsf(s); return a >= 0x1p-95f && a < 0x1p125f; }
+
+// POL: bit 0 non-temporal row loads, bit 1 non-temporal stores (measured: the two rows a wave shares with each vertical neighbour
+// must stay in L2 -- plain loads; scripts/microbench/bw_lean.hip)
+template <int R, int POL, bool INLINE_LIST>
 __global__ void __launch_bounds__(256) cbca_lean2_kernel(const LeanArgs A)
 {
-	constexpr int AUX = NT ? 2 : 0;
+	constexpr int LAUX = (POL & 1) ? 2 : 0, SAUX = (POL & 2) ? 2 : 0;
 	if (!lean_runs(A)) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -413,9 +444,20 @@ __global__ void __launch_bounds__(256) cbca_lean2_kernel(const LeanArgs A)
 	for (int k = 0; k < R + 2; ++k) {
 		const int r = y0 - 1 + k;
 		const bool rok = (unsigned)r < (unsigned)H;
-		v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, (rok & lane_in) ? (cb_u32)(r * W + xs) * 4u : OOB, 0, AUX);
+		v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, (rok & lane_in) ? (cb_u32)(r * W + xs) * 4u : OOB, 0, LAUX);
 		e[k] = __builtin_amdgcn_raw_buffer_load_b32(rv, (rok & eok) ? (cb_u32)(r * W + ecol) * 4u : OOB, 0, 0);
 	}
+	// the wave's listed outputs: its word of the wave table says where they are and how many -- requested now, under the rows
+	const uint32_t *__restrict__ slots = A.hdr + A.slots_words;
+	cb_u32 seg = 0, nent = 0;
+	if (INLINE_LIST) {
+		seg = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w]);
+		nent = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w + 1]);
+	}
+	const bool quick = INLINE_LIST && seg != 0 && seg <= A.cap && nent <= 64u;   // one segment of at most a wave's worth of entries (bit 31 clear)
+	cb_u4 ent = cb_u4{0u, 0u, 0u, 0u};
+	if (quick && (cb_u32)lane < nent) ent = *(const cb_u4 *)(slots + (size_t)(seg + lane) * 4);
+
 	float row[R + 2][6];   // columns xs - 1 .. xs + 4
 #pragma unroll
 	for (int k = 0; k < R + 2; ++k) {
@@ -426,25 +468,43 @@ __global__ void __launch_bounds__(256) cbca_lean2_kernel(const LeanArgs A)
 #pragma unroll
 	for (int k = 0; k < R; ++k) {
 		const int yo = y0 + k;
-		float res[4];
+		float sum[4], res[4];
+		bool fast = true;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			float sum = 0;
-			sum += row[k][j]; sum += row[k][j + 1]; sum += row[k][j + 2];
-			sum += row[k + 1][j]; sum += row[k + 1][j + 1]; sum += row[k + 1][j + 2];
-			sum += row[k + 2][j]; sum += row[k + 2][j + 1]; sum += row[k + 2][j + 2];
-			float q = sum / 9.0f;
-			asm volatile("" : "+v"(q));
-			res[j] = ((inr >> j) & 1u) ? q : row[k + 1][j + 1];
+			float t = 0;
+			t += row[k][j]; t += row[k][j + 1]; t += row[k][j + 2];
+			t += row[k + 1][j]; t += row[k + 1][j + 1]; t += row[k + 1][j + 2];
+			t += row[k + 2][j]; t += row[k + 2][j + 1]; t += row[k + 2][j + 2];
+			sum[j] = t;
+			fast = fast && div9_ok(t);
+			res[j] = div9(t);
 		}
+		if (__any(!fast)) {   // (zeros, denormals, huge values, infinities, NaNs somewhere in the wave's row)
+#pragma unroll
+			for (int j = 0; j < 4; ++j) res[j] = sum[j] / 9.0f;
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) res[j] = ((inr >> j) & 1u) ? res[j] : row[k + 1][j + 1];
 		const bool myrow = yo < y1;
 		const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, myrow ? (yo + 1) * W * 4 : 0, 0x00020000);
 		__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
-		                                       rrow, (myrow & lane_in) ? (cb_u32)(yo * W + xs) * 4u : OOB, 0, AUX);
+		                                       rrow, (myrow & lane_in) ? (cb_u32)(yo * W + xs) * 4u : OOB, 0, SAUX);
 	}
 	if (INLINE_LIST) {
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the same addresses are written again, by other lanes)
-		list_phase(A, w, d, lane);
+		// the listed outputs: their values out of L1 / L2 (this wave and its neighbours have just read those rows), their stores after
+		// the wave's own stores have completed (the same addresses, written by other lanes)
+		if (quick) {
+			const cb_u32 rem = ent.x - (cb_u32)d * (cb_u32)HWi;
+			const bool has = (cb_u32)lane < nent && rem < (cb_u32)HWi;
+			float val = 0.0f;
+			if (has) val = list_entry_value(A, rv, d, ent, rem);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (has) A.vout[(size_t)d * HWi + rem] = val;
+		} else if (seg != 0) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			list_phase(A, w, d, lane);
+		}
 	}
 }
 
@@ -488,11 +548,15 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	A.gyb = (int)cdiv(A.gy, 8);
 	A.gx_rcp = (cb_u32)((((uint64_t)1 << 32) + A.gx - 1) / A.gx);
 	const int64_t waves = (int64_t)A.gx * A.gy * D;
-	A.wtab_words = LH_WORDS;
-	A.slots_words = (uint32_t)((LH_WORDS + 2 * waves + 3) / 4 * 4);
+	// [header LH_WORDS | per-plane slot counters | wave table: 2 words per wave | slots: 16 bytes each, capd per plane]
+	A.cnt_words = LH_WORDS;
+	A.wtab_words = (uint32_t)((LH_WORDS + D + 3) / 4 * 4);
+	A.slots_words = (uint32_t)((A.wtab_words + 2 * waves + 3) / 4 * 4);
 	const int64_t room = (int64_t)plan_bytes / 4 - A.slots_words;
-	A.cap = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(room / 4, 0x3ffffff0));
-	if (cap_limit > 0) A.cap = std::min(A.cap, (uint32_t)cap_limit);   // (test hook: a list that does not fit)
+	int64_t cap = std::max<int64_t>(0, std::min<int64_t>(room / 4, 0x3ffffff0));
+	if (cap_limit > 0) cap = std::min<int64_t>(cap, cap_limit);   // (test hook: a list that does not fit)
+	A.capd = (uint32_t)(cap / std::max(1, D));
+	A.cap = A.capd * (uint32_t)D;
 	A.flags = cs.flag;
 	A.route = route;
 	return A;
@@ -515,7 +579,7 @@ bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes)
 {
 	if ((int64_t)D * H * W >= ((int64_t)1 << 32) || D > 65535) return false;   // (32-bit voxel indices in the entries; the plane is blockIdx.y)
 	const LeanArgs A = lean_args(nullptr, nullptr, plan_bytes, nullptr, nullptr, D, H, W, -1, 0, 0);
-	return A.cap >= 2 && (int64_t)A.gx * A.gy < 65536 && (int64_t)A.gx * A.gy * D < ((int64_t)1 << 30);
+	return A.capd >= 2 && (int64_t)A.gx * A.gy < 65536 && (int64_t)A.gx * A.gy * D < ((int64_t)1 << 30);
 }
 
 // once per pair and direction (before the first pass): the list of outputs whose support is not the minimal 3 x 3
@@ -523,7 +587,7 @@ int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int 
                   hipStream_t st)
 {
 	const LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb > 0 ? rb : MC_LEAN_RB_DEFAULT, cap_limit);
-	const hipError_t e = hipMemsetAsync(plan, 0, (size_t)A.slots_words * 4, st);   // header + wave table
+	const hipError_t e = hipMemsetAsync(plan, 0, (size_t)A.slots_words * 4, st);   // header + slot counters + wave table
 	if (e != hipSuccess) {
 		set_error("cbca_classify: %s", hipGetErrorString(e));
 		return (int)e;
@@ -534,7 +598,7 @@ int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int 
 
 // one aggregation pass: the lean kernel over every output + the listed outputs.  cfg.lean_rb: rows per wave (0 = by size);
 // cfg.lean_variant: bits 0-1 rows in flight 6 / 3 / 9 / 12 (cbca_lean_kernel), bit 2 the listed outputs in a launch of their own,
-// bit 3 cbca_lean2_kernel (short-lived waves of lean_rb = 2 / 4 / 8 rows), bit 4 one band of rows per XCD
+// bit 3 cbca_lean2_kernel (short-lived waves of lean_rb = 2 / 4 / 8 rows), bit 4 one band of rows per XCD, bits 5 / 6 its non-temporal loads / stores
 int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
               int route, hipStream_t st, const CbcaCfg &cfg)
 {
@@ -556,14 +620,22 @@ int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const flo
 			if (nt) hipLaunchKernelGGL((KERNEL<P, true, true>), blocks, dim3(256), 0, st, A); \
 			else hipLaunchKernelGGL((KERNEL<P, false, true>), blocks, dim3(256), 0, st, A); \
 		} } while (0)
+#define MC_LEAN2_GO(P, POL) do { \
+		if (own_launch) hipLaunchKernelGGL((cbca_lean2_kernel<P, POL, false>), blocks, dim3(256), 0, st, A); \
+		else hipLaunchKernelGGL((cbca_lean2_kernel<P, POL, true>), blocks, dim3(256), 0, st, A); } while (0)
+#define MC_LEAN2_POL(P) do { \
+		if (pol == 3) MC_LEAN2_GO(P, 3); else if (pol == 2) MC_LEAN2_GO(P, 2); else if (pol == 1) MC_LEAN2_GO(P, 1); else MC_LEAN2_GO(P, 0); } while (0)
+	const int pol = (variant >> 5) & 3;   // bit 5: non-temporal row loads, bit 6: non-temporal stores (cbca_lean2_kernel)
 	if (v2) {
-		if (rb == 2) MC_LEAN_GO(cbca_lean2_kernel, 2);
-		else if (rb == 8) MC_LEAN_GO(cbca_lean2_kernel, 8);
-		else MC_LEAN_GO(cbca_lean2_kernel, 4);
+		if (rb == 2) MC_LEAN2_POL(2);
+		else if (rb == 8) MC_LEAN2_POL(8);
+		else MC_LEAN2_POL(4);
 	} else if (pf == 1) MC_LEAN_GO(cbca_lean_kernel, 3);
 	else if (pf == 2) MC_LEAN_GO(cbca_lean_kernel, 9);
 	else if (pf == 3) MC_LEAN_GO(cbca_lean_kernel, 12);
 	else MC_LEAN_GO(cbca_lean_kernel, 6);
+#undef MC_LEAN2_POL
+#undef MC_LEAN2_GO
 #undef MC_LEAN_GO
 	int rc = check_launch("cbca_lean");
 	if (rc || !own_launch) return rc;

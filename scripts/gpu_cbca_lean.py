@@ -35,7 +35,7 @@ run("strip kernel", form=1)
 # (a pass that reads the list must use the rows per wave the list was written for: every variant lists first -- form 8 -- the kernels'
 # own times are in the rocprofv3 trace, per kernel name and grid size)
 run("classify + lean<PF=6 inline> rb=auto", form=8, rb=0, d0=0)
-run("classify + lean<PF=6 own list launch> rb=auto", form=8, rb=0, d0=4)
+# cbca_lean2_kernel (bit 3), one band of rows per XCD (bit 4); cache policy: bit 5 non-temporal loads, bit 6 non-temporal stores; bit 2: own list launch
 for rb in (2, 4, 8):
-    for variant, tag in ((8, "linear order"), (24, "a band per XCD"), (12, "linear, own list launch"), (28, "band per XCD, own list launch")):
+    for variant, tag in ((24, "band, plain"), (24 + 64, "band, nt stores"), (24 + 96, "band, nt both"), (8, "linear, plain"), (24 + 4, "band, plain, own list launch")):
         run("classify + lean2<R=%d, %s>" % (rb, tag), form=8, rb=rb, d0=variant)

@@ -63,7 +63,7 @@ def test_lean_rows_per_wave_and_prefetch_depth(mc, oracle, rb, variant):
 
 @pytest.mark.parametrize("H,W,D", [(61, 530, 5), (90, 300, 9), (5, 7, 3), (17, 257, 9), (3, 1030, 5), (140, 130, 3), (1, 9, 2)])
 @pytest.mark.parametrize("rb", [2, 4, 8])
-@pytest.mark.parametrize("variant", [8, 24, 12, 28])   # bit 3: short-lived waves of rb rows, bit 4: one band of rows per XCD, bit 2: own list launch
+@pytest.mark.parametrize("variant", [8, 24, 12, 28, 24 + 96])   # bit 3: short-lived waves of rb rows, bit 4: one band of rows per XCD, bit 2: own list launch, bits 5 / 6: non-temporal loads / stores
 @pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.05), ("blocky", 14, 0.2)])
 def test_lean_short_lived_waves(mc, oracle, H, W, D, rb, variant, mk, L1, tau1):
     """cbca_lean2_kernel: a wave per rb output rows x 256 columns, dispatched in address order / per-XCD bands; images smaller than
