@@ -26,9 +26,8 @@ struct LeanArgs {
 	const float *vin;
 	float *vout;
 	uint32_t *hdr;               // list header (LH_*); behind it the wave table and the slots
-	uint32_t cnt_words;          // word offset of the per-plane slot counters (the slots are allotted per plane: capd each)
-	uint32_t capd;               // slots per plane
-	uint32_t wtab_words;         // word offset of the wave table: per wave of the lean kernel {first segment's slot + 1, its entries | more segments << 31}
+	uint32_t capd;               // slots per plane (the slots are allotted per plane)
+	uint32_t wtab_words;         // word offset of the wave table: per wave of the lean kernel {slot + 1 of its first entry, its entries}
 	uint32_t slots_words;        // word offset of the slots (16 bytes each)
 	uint32_t cap;                // slots the list can hold
 	int D, H, W, direction;
@@ -163,20 +162,15 @@ __device__ __forceinline__ void list_phase(const LeanArgs &A, long long w, int d
 	const int HWi = A.H * A.W;
 	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
 	const uint32_t *__restrict__ slots = A.hdr + A.slots_words;
-	cb_u32 seg = A.hdr[A.wtab_words + 2 * w];   // slot + 1 of the wave's first segment
-	seg = (cb_u32)__builtin_amdgcn_readfirstlane((int)seg);
-	int guard = 0;
-	while (seg != 0 && seg <= A.cap && ++guard < (1 << 20)) {
-		const cb_u4 sh4 = *(const cb_u4 *)(slots + (size_t)(seg - 1) * 4);   // segment header: {entries, next segment's slot + 1}
-		const int n = min((int)__builtin_amdgcn_readfirstlane((int)sh4.x), (int)(A.cap - (seg - 1)) - 1);
-		const cb_u32 next = (cb_u32)__builtin_amdgcn_readfirstlane((int)sh4.y);
-		for (int i = lane; i < n; i += 64) {
-			const cb_u4 e = *(const cb_u4 *)(slots + (size_t)(seg + i) * 4);
-			const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;   // y * W + x
-			if (rem >= (cb_u32)HWi) continue;   // (not this plane's: never written by cbca_classify_kernel)
-			A.vout[(size_t)d * HWi + rem] = list_entry_value(A, rv, d, e, rem);
-		}
-		seg = next;
+	const cb_u32 first = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w]);   // slot + 1 of the wave's first entry
+	cb_u32 n = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w + 1]);
+	if (first == 0 || first > A.cap) return;
+	n = min(n, A.cap - (first - 1));
+	for (cb_u32 i = (cb_u32)lane; i < n; i += 64) {
+		const cb_u4 e = *(const cb_u4 *)(slots + (size_t)(first - 1 + i) * 4);
+		const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;   // y * W + x
+		if (rem >= (cb_u32)HWi) continue;   // (not this plane's: never written by cbca_classify_kernel)
+		A.vout[(size_t)d * HWi + rem] = list_entry_value(A, rv, d, e, rem);
 	}
 }
 
@@ -185,18 +179,21 @@ __device__ __forceinline__ void list_phase(const LeanArgs &A, long long w, int d
 // ---- once per pair and direction: the outputs the lean kernel gets wrong ---------------------------------------------------
 // An output (d, y, x) with a partner has the minimal support iff its combined arms (per-arm minimum of the two images,
 // cbca.hip "Packed arm lengths") are all 1 and the rows above and below have left = right = 1 in its column -- the test of
-// the strip kernel.  Everything else with a partner is listed.  The waves are the lean kernel's (same plane, rows, strip): a
-// wave collects its entries in LDS and appends them 256 and more at a time as a SEGMENT -- one atomic for its slots, a header
-// slot {entries, next segment}, the entries with their supports' shapes (looked up here, once per pair, instead of in every
-// pass) -- chained from the wave's word of the wave table.
+// the strip kernel.  Everything else with a partner is listed.  The waves are the lean kernel's (same plane, rows, strip).
+// Three launches and no atomic (one shared counter for 400 K short-lived waves measured 4 ms, one per plane 2 ms):
+//   PASS 0  every wave COUNTS its listed outputs -> its word of the wave table;
+//   scan    one block per plane turns the counts of the plane's waves into slot numbers (the slots are allotted per plane, capd each);
+//   PASS 1  every wave WRITES its entries -- voxel index and the support's shape, looked up here, once per pair, instead of in
+//           every pass -- into its own run of slots.
+template <int PASS>
 __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 {
-	__shared__ cb_u32 bufs[4][512];
+	__shared__ cb_u32 bufs[PASS ? 4 : 1][PASS ? 512 : 1];
 	if (!cbca_gate(A.flags, A.route)) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	cb_u32 *__restrict__ buf = bufs[wv];
-	if (blockIdx.x == 0 && threadIdx.x == 0) {   // (count, overflow word and wave table were zeroed by the host's memset)
+	cb_u32 *__restrict__ buf = bufs[PASS ? wv : 0];
+	if (PASS == 1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // (the overflow word is the scan's)
 		A.hdr[LH_D] = (uint32_t)A.D; A.hdr[LH_H] = (uint32_t)A.H; A.hdr[LH_W] = (uint32_t)A.W;
 		A.hdr[LH_DIR] = (uint32_t)(A.direction + 1); A.hdr[LH_RB] = (uint32_t)A.rb; A.hdr[LH_MAGIC] = LH_MAGIC_VALUE;
 	}
@@ -208,6 +205,13 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 	const int sh = d * A.direction;
 	const int xs = xb + 4 * lane;
 	const cb_u32 OOB = 0x80000000u;
+	uint32_t *__restrict__ slots = A.hdr + A.slots_words;
+	cb_u32 first = 0, total = 0;   // PASS 1: slot + 1 of the wave's first entry, its entries (0: none -- or the plane's list does not fit)
+	if (PASS == 1) {
+		first = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w]);
+		total = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w + 1]);
+		if (first == 0 || first - 1 + total > ((cb_u32)d + 1u) * A.capd) return;
+	}
 	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
 	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
@@ -224,33 +228,9 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 		const cb_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
 		m[0] = bytemin4(a.x, b.x); m[1] = bytemin4(a.y, b.y); m[2] = bytemin4(a.z, b.z); m[3] = bytemin4(a.w, b.w);
 	};
-	uint32_t *__restrict__ slots = A.hdr + A.slots_words;
-	int cnt = 0;
-	cb_u32 prev = 0;   // slot + 1 of this wave's last segment header
-	cb_u32 first_cnt = 0;
+	int cnt = 0;         // PASS 0: the count; PASS 1: entries waiting in LDS
+	cb_u32 written = 0;  // PASS 1: entries already in their slots
 	auto flush = [&]() {
-		// slots are allotted per plane (one counter per plane: a single counter for 400 K waves is four milliseconds of atomics)
-		cb_u32 local = 0;
-		if (lane == 0) local = atomicAdd(A.hdr + A.cnt_words + d, (cb_u32)cnt + 1u);
-		local = (cb_u32)__builtin_amdgcn_readfirstlane((int)local);
-		if (local + (cb_u32)cnt + 1u > A.capd) {   // the list does not fit: the passes fall back to the strip kernel
-			if (lane == 0) A.hdr[LH_OVERFLOW] = 1u;
-			cnt = 0;
-			return;
-		}
-		const cb_u32 base = (cb_u32)d * A.capd + local;
-		if (lane == 0) {
-			*(cb_u4 *)(slots + (size_t)base * 4) = cb_u4{(cb_u32)cnt, 0u, 0u, 0u};
-			if (prev) {
-				slots[(size_t)(prev - 1) * 4 + 1] = base + 1u;
-				A.hdr[A.wtab_words + 2 * w + 1] = first_cnt | 0x80000000u;   // more than one segment
-			} else {
-				A.hdr[A.wtab_words + 2 * w] = base + 1u;
-				A.hdr[A.wtab_words + 2 * w + 1] = (cb_u32)cnt;
-				first_cnt = (cb_u32)cnt;
-			}
-		}
-		prev = base + 1u;
 		for (int i = lane; i < cnt; i += 64) {
 			const cb_u32 idx = buf[i];
 			const int rem = (int)(idx - (cb_u32)d * (cb_u32)HWi);   // y * W + x
@@ -272,8 +252,9 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 			}
 			if (!fits) { ew[0] = 0xffu; ew[1] = ew[2] = 0u; }
 			else ew[0] |= small ? (0xe0u | (cb_u32)u | ((cb_u32)dn << 2)) : (cb_u32)(u | (dn << 4));
-			*(cb_u4 *)(slots + (size_t)(base + 1 + i) * 4) = cb_u4{idx, ew[0], ew[1], ew[2]};
+			if (written + (cb_u32)i < total) *(cb_u4 *)(slots + (size_t)(first - 1 + written + i) * 4) = cb_u4{idx, ew[0], ew[1], ew[2]};
 		}
+		written += (cb_u32)cnt;
 		cnt = 0;
 	};
 	cb_u32 ma[4], mb[4], mc_[4], md[4];   // rows y - 1, y, y + 1 and, on its way, y + 2
@@ -287,15 +268,54 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 			const bool minimal = mb[j] == 0x01010101u && (ma[j] & 0xffffu) == 0x0101u && (mc_[j] & 0xffffu) == 0x0101u;
 			const bool listed = ((want >> j) & 1u) && !minimal;
 			const unsigned long long bal = __ballot(listed);
-			const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((cb_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)bal, 0));
-			if (listed) buf[pos] = (cb_u32)d * (cb_u32)HWi + (cb_u32)(y * W + xs + j);
+			if (PASS == 1) {
+				const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((cb_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)bal, 0));
+				if (listed) buf[pos] = (cb_u32)d * (cb_u32)HWi + (cb_u32)(y * W + xs + j);
+			}
 			cnt += __builtin_popcountll(bal);
 		}
-		if (cnt >= 256) flush();   // (a row adds at most 256 entries: 512 always hold them)
+		if (PASS == 1 && cnt >= 256) flush();   // (a row adds at most 256 entries: 512 always hold them)
 #pragma unroll
 		for (int j = 0; j < 4; ++j) { ma[j] = mb[j]; mb[j] = mc_[j]; mc_[j] = md[j]; }
 	}
-	if (cnt) flush();
+	if (PASS == 0) {
+		if (lane == 0) A.hdr[A.wtab_words + 2 * w + 1] = (cb_u32)cnt;
+	} else if (cnt) {
+		flush();
+	}
+}
+
+// counts of a plane's waves -> slot numbers: wave table word 0 = slot + 1 of the wave's first entry (0: none).  One block per plane,
+// the plane's npl waves are consecutive in the table; a plane whose entries exceed capd raises the overflow word (the list is then
+// not used: the strip kernel runs the passes).
+__global__ void __launch_bounds__(256) cbca_list_scan_kernel(const LeanArgs A, int npl)
+{
+	__shared__ cb_u32 wsum[4];
+	if (!cbca_gate(A.flags, A.route)) return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int d = blockIdx.x;
+	uint32_t *__restrict__ tab = A.hdr + A.wtab_words + 2 * (size_t)d * npl;
+	cb_u32 running = 0;
+	for (int i0 = 0; i0 < npl; i0 += 256) {
+		const int i = i0 + tid;
+		const cb_u32 c = i < npl ? tab[2 * i + 1] : 0u;
+		cb_u32 incl = c;   // inclusive scan inside the wave, then across the block's four waves
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const cb_u32 t = (cb_u32)__shfl_up((int)incl, o);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wv] = incl;
+		__syncthreads();
+		cb_u32 before = 0, blk = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { if (k < wv) before += wsum[k]; blk += wsum[k]; }
+		const cb_u32 ex = running + before + incl - c;
+		if (i < npl) tab[2 * i] = (c && ex + c <= A.capd) ? (cb_u32)d * A.capd + ex + 1u : 0u;
+		running += blk;
+		__syncthreads();
+	}
+	if (tid == 0 && running > A.capd) A.hdr[LH_OVERFLOW] = 1u;
 }
 
 // ---- per pass: the minimal 3 x 3 mean for every output -------------------------------------------------------------------
@@ -449,14 +469,14 @@ __global__ void __launch_bounds__(256) cbca_lean2_kernel(const LeanArgs A)
 	}
 	// the wave's listed outputs: its word of the wave table says where they are and how many -- requested now, under the rows
 	const uint32_t *__restrict__ slots = A.hdr + A.slots_words;
-	cb_u32 seg = 0, nent = 0;
+	cb_u32 seg = 0, nent = 0;   // slot + 1 of the wave's first entry, its entries
 	if (INLINE_LIST) {
 		seg = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w]);
 		nent = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w + 1]);
 	}
-	const bool quick = INLINE_LIST && seg != 0 && seg <= A.cap && nent <= 64u;   // one segment of at most a wave's worth of entries (bit 31 clear)
+	const bool quick = INLINE_LIST && seg != 0 && seg - 1 + nent <= A.cap && nent <= 64u;   // at most a wave's worth of entries: one lane each
 	cb_u4 ent = cb_u4{0u, 0u, 0u, 0u};
-	if (quick && (cb_u32)lane < nent) ent = *(const cb_u4 *)(slots + (size_t)(seg + lane) * 4);
+	if (quick && (cb_u32)lane < nent) ent = *(const cb_u4 *)(slots + (size_t)(seg - 1 + lane) * 4);
 
 	float row[R + 2][6];   // columns xs - 1 .. xs + 4
 #pragma unroll
@@ -548,9 +568,8 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	A.gyb = (int)cdiv(A.gy, 8);
 	A.gx_rcp = (cb_u32)((((uint64_t)1 << 32) + A.gx - 1) / A.gx);
 	const int64_t waves = (int64_t)A.gx * A.gy * D;
-	// [header LH_WORDS | per-plane slot counters | wave table: 2 words per wave | slots: 16 bytes each, capd per plane]
-	A.cnt_words = LH_WORDS;
-	A.wtab_words = (uint32_t)((LH_WORDS + D + 3) / 4 * 4);
+	// [header LH_WORDS | wave table: 2 words per wave, canonical order (plane, chunk, strip) | slots: 16 bytes each, capd per plane]
+	A.wtab_words = LH_WORDS;
 	A.slots_words = (uint32_t)((A.wtab_words + 2 * waves + 3) / 4 * 4);
 	const int64_t room = (int64_t)plan_bytes / 4 - A.slots_words;
 	int64_t cap = std::max<int64_t>(0, std::min<int64_t>(room / 4, 0x3ffffff0));
@@ -587,12 +606,14 @@ int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int 
                   hipStream_t st)
 {
 	const LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb > 0 ? rb : MC_LEAN_RB_DEFAULT, cap_limit);
-	const hipError_t e = hipMemsetAsync(plan, 0, (size_t)A.slots_words * 4, st);   // header + slot counters + wave table
+	const hipError_t e = hipMemsetAsync(plan, 0, LH_WORDS * 4, st);   // (the header: magic and overflow word; the wave table is written in full)
 	if (e != hipSuccess) {
 		set_error("cbca_classify: %s", hipGetErrorString(e));
 		return (int)e;
 	}
-	hipLaunchKernelGGL(cbca_classify_kernel, lean_grid(A), dim3(256), 0, st, A);
+	hipLaunchKernelGGL(cbca_classify_kernel<0>, lean_grid(A), dim3(256), 0, st, A);
+	hipLaunchKernelGGL(cbca_list_scan_kernel, dim3((unsigned)D), dim3(256), 0, st, A, A.gx * A.gy);
+	hipLaunchKernelGGL(cbca_classify_kernel<1>, lean_grid(A), dim3(256), 0, st, A);
 	return check_launch("cbca_classify");
 }
 
