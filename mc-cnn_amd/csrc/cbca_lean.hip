@@ -101,6 +101,34 @@ __device__ __forceinline__ cb_u32 entry_byte(const cb_u4 &e, int j)
 //   byte 0 = up | down << 4 (< 0xe0)    at most 11 rows, arms up to 13 / 15: bytes 1 .. 11 = left | right << 4 per row
 //   byte 0 = 0xff                       anything else: the arm lengths are looked up
 // Runs are read four values at a time (any 4-byte alignment); the values behind a run's end add -0.0f (x + -0.0f == x).
+// the small class in two halves, so that cbca_lean2_kernel can request an entry's runs before and sum them after its own rows' work:
+// `on` = this lane has a small-class entry (else nothing is requested and the sum is void)
+__device__ __forceinline__ void small_request(const LeanArgs &A, const __amdgpu_buffer_rsrc_t &rv, bool on, const cb_u4 &e, cb_u32 rem, cb_u4 (&v)[4], int (&nn)[4])
+{
+	const cb_u32 b0 = e.y & 0xffu;
+	const int u = (int)(b0 & 3u), rows = on ? u + (int)((b0 >> 2) & 3u) + 1 : 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const cb_u32 lr = entry_byte(e, 1 + k);
+		nn[k] = k < rows ? (int)(lr & 15u) + (int)(lr >> 4) + 1 : 0;
+		v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, k < rows ? (cb_u32)((int)rem + (k - u) * A.W - (int)(lr & 15u)) * 4u : 0x80000000u, 0, 0);
+	}
+}
+__device__ __forceinline__ float small_sum(const cb_u4 (&v)[4], const int (&nn)[4])
+{
+	float sum = 0;
+	int cnt = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		sum += 0 < nn[k] ? __uint_as_float(v[k].x) : -0.0f;
+		sum += 1 < nn[k] ? __uint_as_float(v[k].y) : -0.0f;
+		sum += 2 < nn[k] ? __uint_as_float(v[k].z) : -0.0f;
+		sum += 3 < nn[k] ? __uint_as_float(v[k].w) : -0.0f;
+		cnt += nn[k];
+	}
+	return sum / (float)cnt;
+}
+
 // value of one listed output (entry e of plane d; rem = y * W + x): the reference's loop out of the entry's shape
 __device__ __forceinline__ float list_entry_value(const LeanArgs &A, const __amdgpu_buffer_rsrc_t &rv, int d, const cb_u4 &e, cb_u32 rem)
 {
@@ -474,28 +502,40 @@ __global__ void __launch_bounds__(256) cbca_lean2_kernel(const LeanArgs A)
 		seg = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w]);
 		nent = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w + 1]);
 	}
-	const bool quick = INLINE_LIST && seg != 0 && seg - 1 + nent <= A.cap && nent <= 64u;   // at most a wave's worth of entries: one lane each
+	bool quick = INLINE_LIST && seg != 0 && seg - 1 + nent <= A.cap && nent <= 64u;   // at most a wave's worth of entries: one lane each
 	cb_u4 ent = cb_u4{0u, 0u, 0u, 0u};
 	if (quick && (cb_u32)lane < nent) ent = *(const cb_u4 *)(slots + (size_t)(seg - 1 + lane) * 4);
+	// ... and the runs of the small-class entries (at most four rows of at most four values: nearly all of a texture's entries) behind
+	// the rows: they are lines this wave and its neighbours are fetching anyway, and they arrive while the rows are summed
+	const cb_u32 erem = ent.x - (cb_u32)d * (cb_u32)HWi;
+	const bool ehas = quick && (cb_u32)lane < nent && erem < (cb_u32)HWi;
+	const bool esmall = ehas && (ent.y & 0xf0u) == 0xe0u;
+	if (__any(ehas && !esmall)) quick = false;   // (an entry of another class: the wave's entries go through list_phase, after its rows)
+	cb_u4 ev[4];
+	int enn[4];
+	if (INLINE_LIST) small_request(A, rv, quick && esmall, ent, erem, ev, enn);
 
-	float row[R + 2][6];   // columns xs - 1 .. xs + 4
+	// columns xs - 1 / xs + 4 of every row: the neighbouring lanes' last / first column (lane 0 / 63: the strip's outer columns)
+	float nl[R + 2], nr[R + 2];
 #pragma unroll
 	for (int k = 0; k < R + 2; ++k) {
-		row[k][1] = __uint_as_float(v[k].x); row[k][2] = __uint_as_float(v[k].y); row[k][3] = __uint_as_float(v[k].z); row[k][4] = __uint_as_float(v[k].w);
-		row[k][0] = lane_from_below(row[k][4], __uint_as_float(e[k]));   // lane 0: the strip's left outer column
-		row[k][5] = lane_from_above(row[k][1], __uint_as_float(e[k]));   // lane 63: its right outer column
+		nl[k] = lane_from_below(__uint_as_float(v[k].w), __uint_as_float(e[k]));
+		nr[k] = lane_from_above(__uint_as_float(v[k].x), __uint_as_float(e[k]));
 	}
 #pragma unroll
 	for (int k = 0; k < R; ++k) {
 		const int yo = y0 + k;
+		const float ra[6] = {nl[k], __uint_as_float(v[k].x), __uint_as_float(v[k].y), __uint_as_float(v[k].z), __uint_as_float(v[k].w), nr[k]};
+		const float rb[6] = {nl[k + 1], __uint_as_float(v[k + 1].x), __uint_as_float(v[k + 1].y), __uint_as_float(v[k + 1].z), __uint_as_float(v[k + 1].w), nr[k + 1]};
+		const float rc[6] = {nl[k + 2], __uint_as_float(v[k + 2].x), __uint_as_float(v[k + 2].y), __uint_as_float(v[k + 2].z), __uint_as_float(v[k + 2].w), nr[k + 2]};
 		float sum[4], res[4];
 		bool fast = true;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			float t = 0;
-			t += row[k][j]; t += row[k][j + 1]; t += row[k][j + 2];
-			t += row[k + 1][j]; t += row[k + 1][j + 1]; t += row[k + 1][j + 2];
-			t += row[k + 2][j]; t += row[k + 2][j + 1]; t += row[k + 2][j + 2];
+			t += ra[j]; t += ra[j + 1]; t += ra[j + 2];
+			t += rb[j]; t += rb[j + 1]; t += rb[j + 2];
+			t += rc[j]; t += rc[j + 1]; t += rc[j + 2];
 			sum[j] = t;
 			fast = fast && div9_ok(t);
 			res[j] = div9(t);
@@ -505,22 +545,20 @@ __global__ void __launch_bounds__(256) cbca_lean2_kernel(const LeanArgs A)
 			for (int j = 0; j < 4; ++j) res[j] = sum[j] / 9.0f;
 		}
 #pragma unroll
-		for (int j = 0; j < 4; ++j) res[j] = ((inr >> j) & 1u) ? res[j] : row[k + 1][j + 1];
+		for (int j = 0; j < 4; ++j) res[j] = ((inr >> j) & 1u) ? res[j] : rb[j + 1];
 		const bool myrow = yo < y1;
 		const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, myrow ? (yo + 1) * W * 4 : 0, 0x00020000);
 		__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
 		                                       rrow, (myrow & lane_in) ? (cb_u32)(yo * W + xs) * 4u : OOB, 0, SAUX);
+		__builtin_amdgcn_sched_barrier(0);   // (a row at a time: otherwise every row's sums are hoisted and the registers of all of them are live at once)
 	}
 	if (INLINE_LIST) {
 		// the listed outputs: their values out of L1 / L2 (this wave and its neighbours have just read those rows), their stores after
 		// the wave's own stores have completed (the same addresses, written by other lanes)
 		if (quick) {
-			const cb_u32 rem = ent.x - (cb_u32)d * (cb_u32)HWi;
-			const bool has = (cb_u32)lane < nent && rem < (cb_u32)HWi;
-			float val = 0.0f;
-			if (has) val = list_entry_value(A, rv, d, ent, rem);
+			const float val = small_sum(ev, enn);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (has) A.vout[(size_t)d * HWi + rem] = val;
+			if (ehas) A.vout[(size_t)d * HWi + erem] = val;
 		} else if (seg != 0) {
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			list_phase(A, w, d, lane);
