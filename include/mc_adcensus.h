@@ -288,10 +288,11 @@ int mc_write_pfm(const float *img, int height, int width, const char *fname);
  * the first aggregation pass of a direction for the other 17) behind the packed lengths, 6 / 7 = tile kernel that READS it:
  * `scratch` must be 16-byte aligned and hold mc_cbca_scratch_bytes(H, W) + mc_cbca_plan_bytes(D, H, W) bytes, and a 6 / 7 call
  * must follow a 4 / 5 call with the same arms, D, H, W, direction and scratch.
- * 8 / 9 = the lean + list kernels mc_predict runs on textured pairs (route of the strip kernel, arms <= 13): 8 first lists the
- * outputs whose support is not the minimal 3 x 3 behind the packed lengths (same scratch size as 4 - 7), 9 reads that list; the
- * strip kernel takes over if the list is another problem's or did not fit.  There `rb` = rows per wave, `d0` = bits 0-1 rows in
- * flight (6 / 3 / 9 / 12), bit 2 the listed outputs in a launch of their own, `nd` = slots the list may hold (0 = all of its room).
+ * 8 / 9 = the lean kernel mc_predict runs on textured pairs (route of the strip kernel, arms <= 13): 8 first lists the outputs
+ * whose support is not the minimal 3 x 3 behind the packed lengths (same scratch size as 4 - 7), 9 reads that list; the strip
+ * kernel takes over if the list is another problem's or did not fit.  There `rb` = rows per wave (2 / 4 / 8, else the product's),
+ * `d0` = launch variant (bit 2 the listed outputs in a launch of their own, bit 4 one band of rows per XCD, bits 5 / 6
+ * non-temporal loads / stores), `nd` = slots the list may hold (0 = all of its room).
  * Lets small-shape parity tests reach what the benchmarked sizes and parameter sets select. */
 size_t mc_cbca_plan_bytes(int D, int H, int W);
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,

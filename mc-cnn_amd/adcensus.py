@@ -105,10 +105,10 @@ def cbca_cfg(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, d0=0, nd=0, form
     instantiation, plane range, kernel form (0 what adcensus.cbca does, 1 strip kernel with rb rows per strip, 2 / 3 tile
     kernel short-arm / long-arm instance with rb = geometry variant; these write nothing if an arm exceeds 4 / 13;
     4 / 5 tile kernel that also writes the pair's item order behind the packed lengths, 6 / 7 tile kernel that reads it:
-    a 6 / 7 call must follow a 4 / 5 call on the same arms, shape and direction; 8 / 9 the lean + list kernels of textured pairs:
+    a 6 / 7 call must follow a 4 / 5 call on the same arms, shape and direction; 8 / 9 the lean kernel of textured pairs:
     8 first lists the outputs whose support is not the minimal 3 x 3 behind the packed lengths, 9 reads that list -- the strip
-    kernel takes over if the list is not this problem's or did not fit; rb = rows per wave, d0 = prefetch variant, nd = entries the list
-    may hold)
+    kernel takes over if the list is not this problem's or did not fit; rb = rows per wave (2 / 4 / 8), d0 = launch variant, nd = slots
+    the list may hold)
     -- instead of derived from the problem."""
     _chk(x0c, x1c, vol_in, vol_out)
     D, H, W = vol_out.shape[-3:]

@@ -643,12 +643,12 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	if (rc) return rc;
 	CbcaCfg cfg;
 	cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd;
-	if (form >= 8) {   // lean + list kernels (textures): 8 lists the outputs whose support is not the minimal 3 x 3 behind the packed lengths first, 9 reads that list; rb = rows per wave, d0 = prefetch variant
+	if (form >= 8) {   // lean kernel (textures): 8 lists the outputs whose support is not the minimal 3 x 3 behind the packed lengths first, 9 reads that list
 		const size_t off = align_up(cbca_scratch_bytes(H, W), 256), pb = cbca_plan_bytes(D, H, W);
 		MC_REQUIRE(scratch_bytes >= off + pb, "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu with the list", scratch_bytes, off + pb);
 		MC_REQUIRE((uintptr_t)scratch % 16 == 0, "mc_cbca_ws_cfg: scratch must be 16-byte aligned for the list");
 		MC_REQUIRE(cbca_lean_fits(D, H, W, pb), "mc_cbca_ws_cfg: volume too large for 32-bit list entries");
-		// (forms 8 / 9 take the whole volume; nd > 0 = slots the list may hold, to exercise the fallback; d0: bits 0-1 rows in flight, bit 2 the listed outputs in a launch of their own)
+		// (forms 8 / 9 take the whole volume; rb = rows per wave, d0 = launch variant, nd > 0 = slots the list may hold, to exercise the fallback)
 		cfg.plan = (char *)scratch + off;
 		cfg.plan_bytes = pb;
 		cfg.lean_rb = rb;

@@ -7,10 +7,10 @@
 //   cbca_classify_kernel  (arms only)  LISTS every output with a partner whose support is NOT the minimal 3 x 3, with the
 //                                      support's shape (16 bytes per entry), per wave of the lean kernel, in the pair's plan area;
 //   cbca_lean_kernel      (per pass)   computes the minimal 3 x 3 mean for EVERY output -- nine additions in the reference's
-//                                      order and an IEEE divide, out of a three-row register window, neighbours' columns
-//                                      through DPP: no arm lengths, no LDS, no tests; the plane is read once and written once --
-//                                      and then re-runs the reference's loop for the wave's listed outputs (one lane per
-//                                      entry, values through L1 / L2: the wave has just read those rows) and overwrites them.
+//                                      order and the division by 9, out of registers, neighbours' columns through DPP: no arm
+//                                      lengths, no LDS, no tests; the plane is read once and written once -- and re-runs the
+//                                      reference's loop for the wave's listed outputs (one lane per entry, values through L1 /
+//                                      L2: the wave and its neighbours are reading those rows) and overwrites them.
 // Outputs without a partner are copied through by the lean kernel (adcensus.cu:353-354).  The strip kernel (cbca.hip), which
 // does all of this per pass, remains what adcensus.cbca runs on its own (no state between calls) and the fallback when the
 // list does not fit.
@@ -39,7 +39,7 @@ struct LeanArgs {
 };
 
 // does this launch run?  cbca_gate (the pair's route) and list_valid (the list is this problem's, and complete) with ONE wait: the
-// eight flag words and the eight header words are requested together (the short-lived waves of cbca_lean2_kernel cannot afford a
+// eight flag words and the eight header words are requested together (the short-lived waves of cbca_lean_kernel cannot afford a
 // chain of dependent scalar loads before their rows are requested)
 __device__ __forceinline__ bool lean_runs(const LeanArgs &A)
 {
@@ -101,7 +101,7 @@ __device__ __forceinline__ cb_u32 entry_byte(const cb_u4 &e, int j)
 //   byte 0 = up | down << 4 (< 0xe0)    at most 11 rows, arms up to 13 / 15: bytes 1 .. 11 = left | right << 4 per row
 //   byte 0 = 0xff                       anything else: the arm lengths are looked up
 // Runs are read four values at a time (any 4-byte alignment); the values behind a run's end add -0.0f (x + -0.0f == x).
-// the small class in two halves, so that cbca_lean2_kernel can request an entry's runs before and sum them after its own rows' work:
+// the small class in two halves, so that cbca_lean_kernel can request an entry's runs before and sum them after its own rows' work:
 // `on` = this lane has a small-class entry (else nothing is requested and the sum is void)
 __device__ __forceinline__ void small_request(const LeanArgs &A, const __amdgpu_buffer_rsrc_t &rv, bool on, const cb_u4 &e, cb_u32 rem, cb_u4 (&v)[4], int (&nn)[4])
 {
@@ -346,109 +346,22 @@ __global__ void __launch_bounds__(256) cbca_list_scan_kernel(const LeanArgs A, i
 	if (tid == 0 && running > A.capd) A.hdr[LH_OVERFLOW] = 1u;
 }
 
-// ---- per pass: the minimal 3 x 3 mean for every output -------------------------------------------------------------------
-// One wave owns a plane x 256 columns x rb rows and walks them top to bottom.  A lane holds the four columns 4 lane .. 4 lane + 3
-// of three consecutive rows (one aligned 16-byte load per row, PF rows in flight); the columns to the left and right come from
-// the neighbouring lanes through DPP wave shifts, the strip's two outer columns from one extra 4-byte load in lanes 0 and 63
-// (lines the neighbouring strips read anyway).  Nine additions per output in the reference's order -- rows ascending, x
-// ascending, accumulator starting at +0.0 (adcensus.cu:356-373) -- and an IEEE divide by 9; outputs without a partner are
-// copied through.  What is wrong afterwards -- outputs with another support, among them every output on the image border,
-// where the window reads zeros -- is exactly what cbca_classify_kernel listed for this wave: list_phase overwrites them.
-template <int PF, bool NT, bool INLINE_LIST>
-__global__ void __launch_bounds__(256) cbca_lean_kernel(const LeanArgs A)
-{
-	static_assert(PF % 3 == 0, "the neighbour columns of the three-row window rotate by renaming");
-	constexpr int AUX = NT ? 2 : 0;   // volumes far beyond the 256 MB Infinity Cache are streamed (cbca_strip_kernel)
-	if (!lean_runs(A)) return;
-	const int lane = threadIdx.x & 63;
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	long long w;
-	int d, y0, y1, xb;
-	if (!lean_wave(A, wv, w, d, y0, y1, xb)) return;
-	const int H = A.H, W = A.W;
-	const int HWi = H * W;
-	const int sh = d * A.direction;
-	const int xs = xb + 4 * lane;
-	const cb_u32 OOB = 0x80000000u;
-	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
-	const bool lane_in = xs < W;                                    // (lanes of the last strip beyond the image: nothing to read or write)
-	const int ecol = lane == 0 ? xs - 1 : (lane == 63 ? xs + 4 : -1);   // the strip's outer columns
-	const bool eok = ecol >= 0 && ecol < W;
-	cb_u32 inr = 0;   // bit j: the output has a partner (adcensus.cu:353)
-#pragma unroll
-	for (int j = 0; j < 4; ++j)
-		if (xs + j + sh >= 0 && xs + j + sh < W) inr |= 1u << j;
-
-	struct Stage { cb_u4 v; cb_u32 e; };
-	// No branch around the loads (hipcc's wait counts stay exact: cbca_tile.hip): one 16-byte load wherever the unit starts.  Where W is
-	// not a multiple of 4 the row's last unit ends in the next row's first columns (or, behind the plane, in nothing): those words are
-	// "columns >= W", which only the border output x = W - 1 would use -- and that one is listed.  Rows outside the image: zeros.
-	auto fetch = [&](Stage &st, int r) {
-		const bool rok = (unsigned)r < (unsigned)H;
-		st.v = __builtin_amdgcn_raw_buffer_load_b128(rv, (rok & lane_in) ? (cb_u32)(r * W + xs) * 4u : OOB, 0, AUX);
-		st.e = __builtin_amdgcn_raw_buffer_load_b32(rv, (rok & eok) ? (cb_u32)(r * W + ecol) * 4u : OOB, 0, 0);
-	};
-	// Row r lives in ONE register set from its request to the last output row that uses it: PF rows in flight + the three-row
-	// window = U sets, the row loop unrolled U times, so that a set is requested at one place of the loop body and nowhere else
-	// (with fewer sets, or a second request site before the loop, hipcc places copies at the back edge that wait for every load in
-	// flight).  The loop therefore starts PF rows early on zeroed sets: those rows request rows ra .. ra + PF - 1 and store nothing.
-	constexpr int U = PF + 3;
-	Stage st[U];
-	float nl[3], nr[3];   // the window rows' columns xs - 1 and xs + 4
-#pragma unroll
-	for (int u = 0; u < U; ++u) { st[u].v = cb_u4{0u, 0u, 0u, 0u}; st[u].e = 0u; }
-	// (no branch anywhere in the row loop -- not around the divide of the outputs with a partner, not around the store of the
-	// staged rows that complete no output row of this wave: hipcc's wait counts then count the rows in flight exactly)
-	auto output = [&](int yo, const Stage &a, const Stage &b, const Stage &c, int ia, int ib, int ic) {
-		const float ra_[6] = {nl[ia], __uint_as_float(a.v.x), __uint_as_float(a.v.y), __uint_as_float(a.v.z), __uint_as_float(a.v.w), nr[ia]};
-		const float rb_[6] = {nl[ib], __uint_as_float(b.v.x), __uint_as_float(b.v.y), __uint_as_float(b.v.z), __uint_as_float(b.v.w), nr[ib]};
-		const float rc_[6] = {nl[ic], __uint_as_float(c.v.x), __uint_as_float(c.v.y), __uint_as_float(c.v.z), __uint_as_float(c.v.w), nr[ic]};
-		float res[4];
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			float sum = 0;
-			sum += ra_[j]; sum += ra_[j + 1]; sum += ra_[j + 2];
-			sum += rb_[j]; sum += rb_[j + 1]; sum += rb_[j + 2];
-			sum += rc_[j]; sum += rc_[j + 1]; sum += rc_[j + 2];
-			float q = sum / 9.0f;
-			asm volatile("" : "+v"(q));   // (computed for every lane: otherwise the divide becomes a conditional block)
-			res[j] = ((inr >> j) & 1u) ? q : rb_[j + 1];
-		}
-		const bool myrow = (yo >= y0) & (yo < y1);
-		// stored through a descriptor that ends with the row: the words of a last unit beyond the image are dropped by the range check
-		// (and an empty one for the staged rows that complete no output row of this wave: nothing may pass the check there)
-		const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, myrow ? (yo + 1) * W * 4 : 0, 0x00020000);
-		__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])},
-		                                       rrow, (myrow & lane_in) ? (cb_u32)(yo * W + xs) * 4u : OOB, 0, AUX);
-	};
-	const int ra = y0 - 1;   // first staged row; rows ra .. y1 are staged, row r completes the window of output row r - 1
-	for (int g = ra - PF; g <= y1; g += U) {
-#pragma unroll
-		for (int u = 0; u < U; ++u) {
-			const int r = g + u;
-			const float e = __uint_as_float(st[u].e);
-			nl[u % 3] = lane_from_below(__uint_as_float(st[u].v.w), e);   // lane 0: the strip's left outer column
-			nr[u % 3] = lane_from_above(__uint_as_float(st[u].v.x), e);   // lane 63: its right outer column
-			output(r - 1, st[(u + U - 2) % U], st[(u + U - 1) % U], st[u], (u + 1) % 3, (u + 2) % 3, u % 3);
-			fetch(st[(u + PF) % U], r + PF <= y1 ? r + PF : -1);   // (the set of row r - 3)
-			__builtin_amdgcn_sched_barrier(0);   // (rows stay in program order: hoisted additions of later rows would wait for their loads early)
-		}
-	}
-	if (INLINE_LIST) {
-		// the wave's listed outputs, after its own stores have completed (the same addresses are written again, by other lanes)
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		list_phase(A, w, d, lane);
-	}
-}
-
-// ---- the same pass as short-lived waves --------------------------------------------------------------------------------------
-// What a plain copy reaches on this chip depends on how the waves in flight lie in memory: 5.0 - 5.5 TB/s at 2 x 2 GB for a
-// grid-stride copy of 16 K blocks, 6.3 / 6.7 TB/s (plain / non-temporal) for ONE 16-byte element per thread, dispatched in address
-// order (profiles/r04_bw_sizes.txt).  The kernel above is of the first kind (6 K waves, each walking 125 rows of a region of its
-// own); this one is of the second: a wave owns R output rows x 256 columns, requests its R + 2 rows at once, computes, stores and
-// ends -- hundreds of thousands of waves dispatched in address order (or, order 1, in address order inside one band of rows per
-// XCD, so that the two rows a wave shares with each vertical neighbour come out of that XCD's L2).  The wave's listed outputs
-// follow at once: their rows are the ones it and its neighbours have just read.
+// ---- per pass: the minimal 3 x 3 mean for every output, then the wave's listed outputs ------------------------------------------
+// A wave owns R output rows x 256 columns of one plane: a lane holds the four columns 4 lane .. 4 lane + 3 of the wave's R + 2 rows
+// (one aligned 16-byte load per row, all requested at once); the columns to the left and right come from the neighbouring lanes
+// through DPP wave shifts, the strip's two outer columns from one extra 4-byte load in lanes 0 and 63 (lines the neighbouring strips
+// read anyway).  Nine additions per output in the reference's order -- rows ascending, x ascending, accumulator starting at +0.0
+// (adcensus.cu:356-373) -- and the division by 9; outputs without a partner are copied through.  What is wrong afterwards -- outputs
+// with another support, among them every output on the image border, where the rows outside the image read as zeros -- is exactly
+// what cbca_classify_kernel listed for this wave: their runs are requested with the rows and summed after them.
+//
+// SHORT-LIVED waves, dispatched in address order: what a plain copy reaches on this chip depends on how the waves in flight lie in
+// memory -- 5.0 - 5.5 TB/s at 2 x 2 GB for a grid-stride copy of 16 K blocks, 6.3 / 6.7 TB/s (plain / non-temporal) for ONE 16-byte
+// element per thread (profiles/r04_bw_sizes.txt).  The first form of this kernel (round 4, in the history: 6 K waves, each walking
+// 125 rows of a region of its own through a register ring) was of the first kind and took 0.68 ms per pass alone, 0.85 with its
+// listed outputs at the end (rows long gone from L2); this one 0.54 / 0.60 (profiles/r04_cbca_lean.txt, scripts/microbench/bw_lean.hip).
+// order 1 (one band of rows per XCD, so that the two rows a wave shares with each vertical neighbour come out of that XCD's L2)
+// measured equal to plain address order in the kernel (ahead in the microbenchmark); loads must NOT be non-temporal (the shared rows).
 // s / 9 in three operations: q = s r, e = fma(-9, q, s), q' = fma(e, r, q) with r = RN(1 / 9) -- equal to the IEEE quotient for EVERY
 // float with 2^-95 <= |s| < 2^125 (tests/test_div9.py walks all 2^32 bit patterns); outside that range the IEEE divide.
 __device__ __forceinline__ float div9(float s)
@@ -463,7 +376,7 @@ __device__ __forceinline__ bool div9_ok(float s) { const float a = __builtin_fab
 // POL: bit 0 non-temporal row loads, bit 1 non-temporal stores (measured: the two rows a wave shares with each vertical neighbour
 // must stay in L2 -- plain loads; scripts/microbench/bw_lean.hip)
 template <int R, int POL, bool INLINE_LIST>
-__global__ void __launch_bounds__(256) cbca_lean2_kernel(const LeanArgs A)
+__global__ void __launch_bounds__(256) cbca_lean_kernel(const LeanArgs A)
 {
 	constexpr int LAUX = (POL & 1) ? 2 : 0, SAUX = (POL & 2) ? 2 : 0;
 	if (!lean_runs(A)) return;
@@ -579,14 +492,16 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
 }
 
 
-// rows per wave / launch variant mc_predict uses (cfg.lean_rb = 0 / cfg.lean_variant < 0)
+// rows per wave / launch variant mc_predict uses (cfg.lean_rb = 0 / cfg.lean_variant < 0): measured at 1000 x 1500 x 256, one box
+// (profiles/r04_cbca_lean.txt): 8 rows 0.602 / 0.620 ms (address order / a band per XCD), 4 rows 0.601 / 0.601, 2 rows 0.652 / 0.635;
+// the classification costs 0.54 / 0.88 / 1.3 ms per direction
 #ifndef MC_LEAN_RB_DEFAULT
-#define MC_LEAN_RB_DEFAULT 0        // 0: cbca_lean_kernel with rows per wave by size; 2 / 4 / 8: cbca_lean2_kernel
+#define MC_LEAN_RB_DEFAULT 8
 #endif
 #ifndef MC_LEAN_VARIANT_DEFAULT
 #define MC_LEAN_VARIANT_DEFAULT 0
 #endif
-int cbca_lean_default_rows() { return MC_LEAN_RB_DEFAULT; }
+static int lean_rows(int rb) { return (rb == 2 || rb == 4 || rb == 8) ? rb : MC_LEAN_RB_DEFAULT; }
 
 static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
                           int route, int rb, int cap_limit = 0, int order = 0)
@@ -598,9 +513,7 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	A.hdr = (uint32_t *)plan;
 	A.D = D; A.H = H; A.W = W; A.direction = direction;
 	A.gx = (int)cdiv(W, 256);
-	// rows per wave: 2 / rb of the rows are read twice; at least ~12 K waves
-	const int64_t gy_min = cdiv((int64_t)12288, (int64_t)A.gx * D);
-	A.rb = rb > 0 ? rb : (int)std::min<int64_t>(128, std::max<int64_t>(16, cdiv((int64_t)H, gy_min)));
+	A.rb = lean_rows(rb);
 	A.gy = (int)cdiv(H, A.rb);
 	A.order = order;
 	A.gyb = (int)cdiv(A.gy, 8);
@@ -622,7 +535,8 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 // rows per wave of the lean / classify kernels for a problem (rb > 0: forced): the list is valid for this value only
 int cbca_lean_rows(int D, int H, int W, int rb)
 {
-	return lean_args(nullptr, nullptr, 0, nullptr, nullptr, D, H, W, -1, 0, rb > 0 ? rb : MC_LEAN_RB_DEFAULT).rb;
+	(void)D; (void)H; (void)W;
+	return lean_rows(rb);
 }
 
 // blocks of 4 waves: x over one plane's (chunk, strip) pairs -- order 1: eight bands of gyb chunks, band = blockIdx.x & 7 --, y = plane
@@ -643,7 +557,7 @@ bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes)
 int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, int rb, int cap_limit,
                   hipStream_t st)
 {
-	const LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb > 0 ? rb : MC_LEAN_RB_DEFAULT, cap_limit);
+	const LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb, cap_limit);
 	const hipError_t e = hipMemsetAsync(plan, 0, LH_WORDS * 4, st);   // (the header: magic and overflow word; the wave table is written in full)
 	if (e != hipSuccess) {
 		set_error("cbca_classify: %s", hipGetErrorString(e));
@@ -655,47 +569,31 @@ int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int 
 	return check_launch("cbca_classify");
 }
 
-// one aggregation pass: the lean kernel over every output + the listed outputs.  cfg.lean_rb: rows per wave (0 = by size);
-// cfg.lean_variant: bits 0-1 rows in flight 6 / 3 / 9 / 12 (cbca_lean_kernel), bit 2 the listed outputs in a launch of their own,
-// bit 3 cbca_lean2_kernel (short-lived waves of lean_rb = 2 / 4 / 8 rows), bit 4 one band of rows per XCD, bits 5 / 6 its non-temporal loads / stores
+// one aggregation pass: the lean kernel over every output + the listed outputs.  cfg.lean_rb: rows per wave (2 / 4 / 8; anything else:
+// the default); cfg.lean_variant: bit 2 the listed outputs in a launch of their own, bit 4 one band of rows per XCD, bits 5 / 6
+// non-temporal loads / stores
 int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
               int route, hipStream_t st, const CbcaCfg &cfg)
 {
-	const int variant = cfg.lean_variant >= 0 ? cfg.lean_variant : (MC_LEAN_VARIANT_DEFAULT | (MC_LEAN_RB_DEFAULT ? 8 : 0));
-	const bool v2 = (variant & 8) != 0;
+	const int variant = cfg.lean_variant >= 0 ? cfg.lean_variant : MC_LEAN_VARIANT_DEFAULT;
 	const int order = (variant & 16) ? 1 : 0;
-	int rb = cfg.lean_rb > 0 ? cfg.lean_rb : MC_LEAN_RB_DEFAULT;
-	if (v2 && rb != 2 && rb != 4 && rb != 8) rb = 4;
+	const int rb = lean_rows(cfg.lean_rb);
 	const LeanArgs A = lean_args(packed, (void *)plan, plan_bytes, vin, vout, D, H, W, direction, route, rb, cfg.nd, order);
-	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)D * H * W * 4 > ((int64_t)768 << 20);
 	const dim3 blocks = lean_grid(A);
 	const bool own_launch = (variant & 4) != 0;
-	const int pf = variant & 3;
-#define MC_LEAN_GO(KERNEL, P) do { \
-		if (own_launch) { \
-			if (nt) hipLaunchKernelGGL((KERNEL<P, true, false>), blocks, dim3(256), 0, st, A); \
-			else hipLaunchKernelGGL((KERNEL<P, false, false>), blocks, dim3(256), 0, st, A); \
-		} else { \
-			if (nt) hipLaunchKernelGGL((KERNEL<P, true, true>), blocks, dim3(256), 0, st, A); \
-			else hipLaunchKernelGGL((KERNEL<P, false, true>), blocks, dim3(256), 0, st, A); \
-		} } while (0)
 #define MC_LEAN2_GO(P, POL) do { \
-		if (own_launch) hipLaunchKernelGGL((cbca_lean2_kernel<P, POL, false>), blocks, dim3(256), 0, st, A); \
-		else hipLaunchKernelGGL((cbca_lean2_kernel<P, POL, true>), blocks, dim3(256), 0, st, A); } while (0)
+		if (own_launch) hipLaunchKernelGGL((cbca_lean_kernel<P, POL, false>), blocks, dim3(256), 0, st, A); \
+		else hipLaunchKernelGGL((cbca_lean_kernel<P, POL, true>), blocks, dim3(256), 0, st, A); } while (0)
 #define MC_LEAN2_POL(P) do { \
 		if (pol == 3) MC_LEAN2_GO(P, 3); else if (pol == 2) MC_LEAN2_GO(P, 2); else if (pol == 1) MC_LEAN2_GO(P, 1); else MC_LEAN2_GO(P, 0); } while (0)
-	const int pol = (variant >> 5) & 3;   // bit 5: non-temporal row loads, bit 6: non-temporal stores (cbca_lean2_kernel)
-	if (v2) {
+	const int pol = (variant >> 5) & 3;   // bit 5: non-temporal row loads, bit 6: non-temporal stores (cbca_lean_kernel)
+	{
 		if (rb == 2) MC_LEAN2_POL(2);
 		else if (rb == 8) MC_LEAN2_POL(8);
 		else MC_LEAN2_POL(4);
-	} else if (pf == 1) MC_LEAN_GO(cbca_lean_kernel, 3);
-	else if (pf == 2) MC_LEAN_GO(cbca_lean_kernel, 9);
-	else if (pf == 3) MC_LEAN_GO(cbca_lean_kernel, 12);
-	else MC_LEAN_GO(cbca_lean_kernel, 6);
+	}
 #undef MC_LEAN2_POL
 #undef MC_LEAN2_GO
-#undef MC_LEAN_GO
 	int rc = check_launch("cbca_lean");
 	if (rc || !own_launch) return rc;
 	hipLaunchKernelGGL(cbca_list_kernel, blocks, dim3(256), 0, st, A);

@@ -34,8 +34,8 @@ def run(tag, **kw):
 run("strip kernel", form=1)
 # (a pass that reads the list must use the rows per wave the list was written for: every variant lists first -- form 8 -- the kernels'
 # own times are in the rocprofv3 trace, per kernel name and grid size)
-run("classify + lean<PF=6 inline> rb=auto", form=8, rb=0, d0=0)
-# cbca_lean2_kernel (bit 3), one band of rows per XCD (bit 4); cache policy: bit 5 non-temporal loads, bit 6 non-temporal stores; bit 2: own list launch
+# every variant lists first (form 8): a pass that reads the list must use the rows per wave the list was written for
+# lean_variant: bit 2 the listed outputs in a launch of their own, bit 4 one band of rows per XCD, bits 5 / 6 non-temporal loads / stores
 for rb in (2, 4, 8):
-    for variant, tag in ((24, "band, plain"), (24 + 64, "band, nt stores"), (24 + 96, "band, nt both"), (8, "linear, plain"), (24 + 4, "band, plain, own list launch")):
-        run("classify + lean2<R=%d, %s>" % (rb, tag), form=8, rb=rb, d0=variant)
+    for variant, tag in ((0, "address order"), (16, "band per XCD"), (64, "address order, nt stores"), (4, "address order, own list launch")):
+        run("classify + lean<R=%d, %s>" % (rb, tag), form=8, rb=rb, d0=variant)

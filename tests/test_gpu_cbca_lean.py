@@ -3,7 +3,7 @@ whose support is not the minimal 3 x 3 are listed once per direction (form 8), e
 everywhere out of a register window and re-runs the reference's loop for the listed outputs (forms 8 and 9) -- against the
 oracle, bit for bit: textures (few listed outputs), real-scene and blocky arms (most outputs listed), images smaller than a
 strip, ragged widths (W not a multiple of 4: the row's last unit ends in the next row), both directions, both cache policies,
-every prefetch depth, rows per wave down to one, special values; a list that does not fit / is another problem's (strip kernel
+every wave geometry and launch variant, special values; a list that does not fit / is another problem's (strip kernel
 takes over)."""
 import numpy as np
 import pytest
@@ -47,9 +47,9 @@ def test_lean_and_list(mc, oracle, H, W, D, mk, L1, tau1):
         assert same_bits(got, want), diff_report(got, want, "pass reading the list, dir=%d" % direction)
 
 
-@pytest.mark.parametrize("rb", [1, 2, 3, 7, 16, 64])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6, 7])   # bits 0-1: rows in flight 6 / 3 / 9 / 12, bit 2: the listed outputs in a launch of their own
-def test_lean_rows_per_wave_and_prefetch_depth(mc, oracle, rb, variant):
+@pytest.mark.parametrize("rb", [0, 2, 4, 8, 5])          # rows per wave (anything but 2 / 4 / 8: the product's choice)
+@pytest.mark.parametrize("variant", [0, 4, 16, 20, 96])   # bit 2: the listed outputs in a launch of their own, bit 4: a band of rows per XCD, bits 5 / 6: non-temporal loads / stores
+def test_lean_rows_per_wave_and_launch_variants(mc, oracle, rb, variant):
     H, W, D = 61, 530, 5
     x0, x1 = smooth_pair(H, W, 8, seed=3)
     x0c, x1c = oracle.cross(x0, 14, 0.05), oracle.cross(x1, 14, 0.05)
@@ -63,11 +63,11 @@ def test_lean_rows_per_wave_and_prefetch_depth(mc, oracle, rb, variant):
 
 @pytest.mark.parametrize("H,W,D", [(61, 530, 5), (90, 300, 9), (5, 7, 3), (17, 257, 9), (3, 1030, 5), (140, 130, 3), (1, 9, 2)])
 @pytest.mark.parametrize("rb", [2, 4, 8])
-@pytest.mark.parametrize("variant", [8, 24, 12, 28, 24 + 96])   # bit 3: short-lived waves of rb rows, bit 4: one band of rows per XCD, bit 2: own list launch, bits 5 / 6: non-temporal loads / stores
+@pytest.mark.parametrize("variant", [0, 16, 4, 20, 16 + 96])   # bit 4: one band of rows per XCD, bit 2: own list launch, bits 5 / 6: non-temporal loads / stores
 @pytest.mark.parametrize("mk,L1,tau1", [("smooth", 14, 0.05), ("blocky", 14, 0.2)])
-def test_lean_short_lived_waves(mc, oracle, H, W, D, rb, variant, mk, L1, tau1):
-    """cbca_lean2_kernel: a wave per rb output rows x 256 columns, dispatched in address order / per-XCD bands; images smaller than
-    eight bands, ragged widths, both directions, a second volume out of the same list"""
+def test_lean_wave_geometries(mc, oracle, H, W, D, rb, variant, mk, L1, tau1):
+    """a wave per rb output rows x 256 columns, dispatched in address order / per-XCD bands; images smaller than eight bands, ragged
+    widths, both directions, a second volume out of the same list"""
     x0, x1 = pair(mk, H, W, D)
     x0c, x1c = oracle.cross(x0, L1, tau1), oracle.cross(x1, L1, tau1)
     vl, vr = raw_volumes(D, H, W, seed=5)
@@ -124,9 +124,9 @@ def test_lean_falls_back_to_the_strip_kernel(mc, oracle):
     got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, vr, 1)
     assert same_bits(got, want), diff_report(got, want, "list of the other direction")
     out = torch.full((1, D, H, W), -7.0, device="cuda")
-    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=7, form=8)
+    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=4, form=8)
     out = torch.full((1, D, H, W), -7.0, device="cuda")
-    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=9, form=9)   # the list on the scratch was written for 7 rows per wave
+    mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vl), out, -1, rb=8, form=9)   # the list on the scratch was written for 4 rows per wave
     got, want = out.cpu().numpy(), oracle.cbca(x0c, x1c, vl, -1)
     assert same_bits(got, want), diff_report(got, want, "list of another wave geometry")
     for Hf, Wf, Df in ((64, 300, 2), (200, 600, 1)):
