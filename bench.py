@@ -221,24 +221,28 @@ def stage_times(step, reps):
 _COPY_RATE = {}
 
 
-def copy_rate(device, nbytes):
+def copy_rate(device, nbytes, how="torch"):
     """The box's device-to-device copy rate for a working set of the workload's size ('measure achievable
-    with a device-copy kernel on the box and report against both'): read + written bytes per second of
-    dst.copy_(src) over two buffers of nbytes each, best of 10 after 3 warm-ups.  Boxes of the pool differ by up to
-    15 %, and buffers that fit the 256 MB Infinity Cache copy faster than HBM streams."""
+    with a device-copy kernel on the box and report against both'): read + written bytes per second over two buffers of
+    nbytes each, best of 10 after 3 warm-ups.  how = "torch": dst.copy_(src), a grid-stride kernel -- what rounds 1-3 quoted
+    (4.8 - 5.5 TB/s at 2 x 1.5 GB); how = "element": one 16-byte element per thread in address order (the library's mc_scale
+    with factor 1), the form the guide's 6.29 TB/s is reached in (profiles/r04_bw_sizes.txt).  Boxes of the pool differ by up
+    to 15 %, and buffers that fit the 256 MB Infinity Cache copy faster than HBM streams."""
     import torch
-    key = (str(device), int(nbytes))
+    key = (str(device), int(nbytes), how)
     if key not in _COPY_RATE:
-        n = max(int(nbytes) // 4, 1 << 20)
+        import mc_cnn_amd as mc
+        n = max(int(nbytes) // 16 * 4, 1 << 20)
         src = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
         dst = torch.empty_like(src)
+        go = (lambda: dst.copy_(src)) if how == "torch" else (lambda: mc.adcensus.scale(src, dst, 1.0))
         for _ in range(3):
-            dst.copy_(src)
+            go()
         best = float("inf")
         for _ in range(10):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dst.copy_(src)
+            go()
             e1.record()
             e1.synchronize()
             best = min(best, e0.elapsed_time(e1))
@@ -338,10 +342,11 @@ def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None, xb=
         rec["frac_two_bounds"] = kernels["cbca"]["frac_two_bounds"]
         rec["bound_ms"] = kernels["cbca"]["bound_ms"]
     if device is not None:  # the same figures against what a plain copy of one volume reaches on THIS box
-        cr = copy_rate(device, 4 * D * H * W)
-        rec["box_copy"] = dict(GBs=round(cr, 1), working_set_bytes=2 * 4 * D * H * W, frac_of_peak=round(cr / HBM_PEAK_GBS, 4),
-                               achieved_over_copy=round(achieved / cr, 4),
-                               note="dst.copy_(src) over two buffers of one volume each, best of 10")
+        cr, ce = copy_rate(device, 4 * D * H * W), copy_rate(device, 4 * D * H * W, "element")
+        rec["box_copy"] = dict(GBs=round(ce, 1), torch_copy_GBs=round(cr, 1), working_set_bytes=2 * 4 * D * H * W, frac_of_peak=round(ce / HBM_PEAK_GBS, 4),
+                               achieved_over_copy=round(achieved / ce, 4),
+                               note="two buffers of one volume each, best of 10: GBs = one 16-byte element per thread in address order (mc_scale), "
+                                    "torch_copy_GBs = dst.copy_(src), a grid-stride kernel (the figure rounds 1-3 quoted)")
     return rec
 
 
@@ -425,8 +430,9 @@ def north_star_record(device, steps=5, with_cpu=True):
                verify=verify_against_reference(cfg, xb, kw, prm, D, ws, "mb_slow"))
     del ws, xb, kw
     torch.cuda.empty_cache()
-    cr = copy_rate(device, V)   # what a plain copy of one volume reaches on this box
+    cr = copy_rate(device, V, "element")   # what a plain copy of one volume reaches on this box (one 16-byte element per thread, address order)
     rec["per_volume"]["box_copy_GBs"] = round(cr, 1)
+    rec["per_volume"]["box_torch_copy_GBs"] = round(copy_rate(device, V), 1)
     rec["per_volume"]["sweep_over_box_copy"] = round(budget / (sweep_ms * 1e-3) / 1e9 / cr, 4)
     rec["pair"] = PAIR_NOTE["texture"]
     if with_cpu:   # the oracle on a 64-row band of this very workload (full width, full disp_max, 2 + 16 iterations): ~20-30 s of host time
