@@ -341,9 +341,17 @@ static void launch_pass(const SgmPassArgs &A, bool vec, hipStream_t st)
 	const int waves = A.nvol * nlines * (DUAL ? 2 : 1);
 	const dim3 grid(cdiv(waves, 4)), block(256);
 	// fewer waves than SIMDs (1024): nothing but prefetch depth hides HBM latency
-	// measured on MI355X (KITTI 370x1226x228): 4 steps ahead for the horizontal and the up sweep, 16 for the down sweep
-	// (three loads per step)
-	const int U = DIRN == 2 ? 16 : 4;
+	// measured on MI355X, A/B on one box (round 4): the depth matters little once >= 4 -- KITTI 370x1226x228 all four
+	// sweeps 2.016 ms at (horizontal 4, up 4), 2.024 at (8, 4), 2.009 at (4, 8), 1.982 at (8, 16), 2.008 at (16, 8), the down
+	// sweep (three loads per step) at 16 throughout; 1500x1000x256 within 1 % either way.  The sweeps run at what the
+	// memory system gives long-lived waves that each walk their own line (4.3-5.1 TB/s), not at a latency bound.
+#ifndef MC_SGM_U_H
+#define MC_SGM_U_H 8
+#endif
+#ifndef MC_SGM_U_UP
+#define MC_SGM_U_UP 16
+#endif
+	const int U = DIRN == 2 ? 16 : (DIRN == 3 ? MC_SGM_U_UP : MC_SGM_U_H);
 #define MC_SGM_GO(VPL_, VEC_, U_) \
 	hipLaunchKernelGGL((sgm_pass_kernel<DIRN, VPL_, MODE, ARGMIN, VEC_, U_, DUAL>), grid, block, 0, st, A)
 	if (A.D <= 256) {
