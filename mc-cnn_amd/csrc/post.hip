@@ -344,14 +344,17 @@ template <int K> __device__ __forceinline__ void ray_rank_step(float v, int inb,
 	eq += (oin && ov == v) ? 1 : 0;
 }
 
+// The walk in integers: the reference accumulates xx += dx in float with dx in {0, +-0.5, +-1} from an integer start, so every
+// xx is an exact multiple of 0.5 and round(xx) (half away from zero) = (X2 + 1 + (X2 >> 31)) >> 1 for X2 = 2 xx -- the same pixels,
+// without the float rounding sequence.  The mark is fetched through a buffer whose range check answers 0 ("not a mismatch")
+// for a position outside the image, so the loop has one exit test and no nested regions.
 __global__ void __launch_bounds__(256) interp_mis_rays_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
-                                                              float *__restrict__ out, int64_t size, int H, int W)
+                                                              float *__restrict__ out, int size, int H, int W)
 {
-	// direction (dx, dy) of ray k, adcensus.cu:1013-1030
-	const float dirx[16] = {0, -0.5f, -1, -1, -1, -1, -1, -0.5f, 0, 0.5f, 1, 1, 1, 1, 1, 0.5f};
-	const float diry[16] = {1, 1, 1, 0.5f, 0, -0.5f, -1, -1, -1, -1, -1, -0.5f, 0, 0.5f, 1, 1};
-	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const int64_t id = t >> 4;
+	// direction (dx, dy) of ray k in half pixels, adcensus.cu:1013-1030:
+	// dx = {0, -.5, -1, -1, -1, -1, -1, -.5, 0, .5, 1, 1, 1, 1, 1, .5}, dy = {1, 1, 1, .5, 0, -.5, -1, -1, -1, -1, -1, -.5, 0, .5, 1, 1}
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	const int id = t >> 4;
 	const int ray = (int)(threadIdx.x & 15);
 	if (id >= size) return;
 	const bool mis = outlier[id] == 2;
@@ -359,17 +362,23 @@ __global__ void __launch_bounds__(256) interp_mis_rays_kernel(const float *__res
 		if (ray == 0) out[id] = d0[id];
 		return;
 	}
-	const int x = (int)(id % W), y = (int)(id / W);
-	const float dx = dirx[ray], dy = diry[ray];
-	float xx = (float)x, yy = (float)y;
+	const int hx[16] = {0, -1, -2, -2, -2, -2, -2, -1, 0, 1, 2, 2, 2, 2, 2, 1};
+	const int hy[16] = {2, 2, 2, 1, 0, -1, -2, -2, -2, -2, -2, -1, 0, 1, 2, 2};
+	const int x = id % W, y = id / W;
+	const int sx = hx[ray], sy = hy[ray];
+	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)outlier, 0, size * 4, 0x00020000);
+	int X2 = 2 * x, Y2 = 2 * y;
 	int xi = x, yi = y;
-	while (0 <= yi && yi < H && 0 <= xi && xi < W && outlier[yi * W + xi] == 2) {
-		xx += dx;
-		yy += dy;
-		xi = (int)roundf(xx);
-		yi = (int)roundf(yy);
+	bool inb = true;                 // the start pixel is a mismatch: the first test passes by construction
+	for (;;) {
+		X2 += sx;
+		Y2 += sy;
+		xi = (X2 + 1 + (X2 >> 31)) >> 1;
+		yi = (Y2 + 1 + (Y2 >> 31)) >> 1;
+		inb = (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W;
+		const unsigned o = __builtin_amdgcn_raw_buffer_load_b32(ro, inb ? (__umul24((unsigned)yi, (unsigned)W) + (unsigned)xi) * 4u : 0x80000000u, 0, 0);   // H*W < 2^27
+		if (__uint_as_float(o) != 2.0f) break;
 	}
-	const int inb = (0 <= yi && yi < H && 0 <= xi && xi < W) ? 1 : 0;
 	const float v = inb ? d0[yi * W + xi] : 0.0f;
 	// all 16 lanes of this pixel are here (mis is uniform over the row of 16)
 	int less = 0, eq = inb;
@@ -391,7 +400,8 @@ __global__ void __launch_bounds__(256) interp_mis_rays_kernel(const float *__res
 int interpolate_mismatch(const float *d0, const float *outlier, float *out, int H, int W, hipStream_t st)
 {
 	const int64_t size = (int64_t)H * W;
-	hipLaunchKernelGGL(interp_mis_rays_kernel, dim3(cdiv(size * 16, 256)), dim3(256), 0, st, d0, outlier, out, size, H, W);
+	MC_REQUIRE(size * 16 < ((int64_t)1 << 31), "interpolate_mismatch: %dx%d pixels x 16 rays do not fit a 32-bit index", H, W);
+	hipLaunchKernelGGL(interp_mis_rays_kernel, dim3(cdiv(size * 16, 256)), dim3(256), 0, st, d0, outlier, out, (int)size, H, W);
 	return check_launch("interpolate_mismatch");
 }
 
@@ -604,8 +614,93 @@ __global__ void __launch_bounds__(64 * M2_TR) mean2d_kernel(const float *__restr
 		if (yb + o < H) out[(int64_t)(yb + o) * W + x] = sum[o] / cnt[o];
 }
 
+// The table radii (kr = 6, 9, 14, 18, 24: every blur_sigma of main.lua:68-295) as compile-time sizes: one output per thread,
+// 64 x 8 outputs per block of 8 waves (twice the waves of the kernel above: at KITTI size that one leaves 2.3 waves per
+// SIMD on average and a VALU instruction every 5.6 cycles -- r03_kitti_fast_pmc.csv).  A tap is four VALU instructions: the gate
+// narrows EXEC (v_cmpx) and the two accumulations run under it with the weight as a scalar operand, so a tap that does
+// not count is skipped instead of adding -0.0, and the weights come through the scalar cache (one s_load_dwordx8 per 8 taps)
+// instead of LDS.  Same taps in the same order, same FMA: bit-identical to the kernel above.
+#define MC_M2_TAP(i) \
+	"v_sub_f32 %[d], %[v" #i "], %[c]\n\tv_cmpx_lt_f32_e64 vcc, |%[d]|, %[a]\n\tv_fmac_f32 %[s], %[w" #i "], %[v" #i "]\n\t" \
+	"v_add_f32 %[n], %[w" #i "], %[n]\n\ts_mov_b64 exec, %[e]\n\t"
+__device__ __forceinline__ void mean2d_taps8(float &sum, float &cnt, const float (&v)[8], const float (&w)[8], float c, float alpha2,
+                                             unsigned long long ex)
+{
+	float d;
+	asm volatile(MC_M2_TAP(0) MC_M2_TAP(1) MC_M2_TAP(2) MC_M2_TAP(3) MC_M2_TAP(4) MC_M2_TAP(5) MC_M2_TAP(6) MC_M2_TAP(7)
+	             : [s] "+v"(sum), [n] "+v"(cnt), [d] "=&v"(d)
+	             : [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]),
+	               [v7] "v"(v[7]), [w0] "s"(w[0]), [w1] "s"(w[1]), [w2] "s"(w[2]), [w3] "s"(w[3]), [w4] "s"(w[4]), [w5] "s"(w[5]),
+	               [w6] "s"(w[6]), [w7] "s"(w[7]), [c] "v"(c), [a] "s"(alpha2), [e] "s"(ex)
+	             : "vcc");
+}
+__device__ __forceinline__ void mean2d_tap1(float &sum, float &cnt, float v0, float w0, float c, float alpha2, unsigned long long ex)
+{
+	float d;
+	asm volatile(MC_M2_TAP(0) : [s] "+v"(sum), [n] "+v"(cnt), [d] "=&v"(d)
+	             : [v0] "v"(v0), [w0] "s"(w0), [c] "v"(c), [a] "s"(alpha2), [e] "s"(ex)
+	             : "vcc");
+}
+#undef MC_M2_TAP
+
+template <int KR>
+__global__ void __launch_bounds__(512) mean2d_taps_kernel(const float *__restrict__ img, const float *__restrict__ kernel,
+                                                          float *__restrict__ out, int H, int W, float alpha2)
+{
+	constexpr int KS = 2 * KR + 1, TW = 64 + 2 * KR, TH = 8 + 2 * KR, TS = TW + 1;
+	__shared__ float tile[TH * TS];
+	const int bx = blockIdx.x * 64, by = blockIdx.y * 8;
+	const float FAR = 1e30f;                     // |FAR - c| < alpha2 is false for any disparity c
+	for (int i = threadIdx.x; i < TH * TW; i += 512) {
+		const int ty = i / TW, tx = i - ty * TW;
+		const int gx = bx + tx - KR, gy = by + ty - KR;
+		tile[ty * TS + tx] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(int64_t)gy * W + gx] : FAR;
+	}
+	__syncthreads();
+	const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+	const int x = bx + lx, y = by + ly;
+	if (x >= W || y >= H) return;
+	const unsigned long long ex = __builtin_amdgcn_read_exec();   // the lanes that own an output: restored after every tap
+	const float c = tile[(ly + KR) * TS + lx + KR];
+	float sum = 0.0f, cnt = 0.0f;
+	const float *col = tile + ly * TS + lx;
+	for (int ix = 0; ix < KS; ++ix, ++col) {
+		const float *wc = kernel + ix * KS;      // uniform: scalar loads
+#pragma unroll
+		for (int j0 = 0; j0 + 8 <= KS; j0 += 8) {
+			float v[8], w[8];
+#pragma unroll
+			for (int g = 0; g < 8; ++g) {
+				v[g] = col[(j0 + g) * TS];
+				w[g] = wc[j0 + g];
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			mean2d_taps8(sum, cnt, v, w, c, alpha2, ex);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+#pragma unroll
+		for (int j = KS / 8 * 8; j < KS; ++j) mean2d_tap1(sum, cnt, col[j * TS], wc[j], c, alpha2, ex);
+	}
+	out[(int64_t)y * W + x] = sum / cnt;
+}
+
+template <int KR>
+static int mean2d_taps(const float *img, const float *kernel, float *out, int H, int W, float alpha2, hipStream_t st)
+{
+	hipLaunchKernelGGL(mean2d_taps_kernel<KR>, dim3(cdiv(W, 64), cdiv(H, 8)), dim3(512), 0, st, img, kernel, out, H, W, alpha2);
+	return check_launch("mean2d");
+}
+
 int mean2d(const float *img, const float *kernel, float *out, int H, int W, int ks, float alpha2, hipStream_t st)
 {
+	switch (ks) {
+	case 13: return mean2d_taps<6>(img, kernel, out, H, W, alpha2, st);
+	case 19: return mean2d_taps<9>(img, kernel, out, H, W, alpha2, st);
+	case 29: return mean2d_taps<14>(img, kernel, out, H, W, alpha2, st);
+	case 37: return mean2d_taps<18>(img, kernel, out, H, W, alpha2, st);
+	case 49: return mean2d_taps<24>(img, kernel, out, H, W, alpha2, st);
+	default: break;   // any other size: the kernel with run-time sizes
+	}
 	const int kr = ks / 2;
 	const size_t lds =
 	    ((size_t)(M2_TR * M2_OY + 2 * kr) * (64 + 2 * kr + 1) + (size_t)ks * (ks + 2 * (M2_OY - 1))) * sizeof(float);

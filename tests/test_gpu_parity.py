@@ -221,7 +221,7 @@ def test_post_chain(mc, oracle, H, W, D):
         assert_same(host(med), oracle.median2d(want_sub, k), "median%d" % k)
     med = mc.adcensus.median2d(sub, 5)
     want_med = oracle.median2d(want_sub, 5)
-    for sigma, t in ((1.67, 2.0), (5.99, 6.0), (7.74, 5.0)):
+    for sigma, t in ((1.0, 2.0), (1.67, 2.0), (2.78, 3.0), (4.64, 5.0), (5.99, 6.0), (7.74, 5.0)):   # 1.0: the run-time-size kernel
         k = mc.adcensus.gaussian(sigma)
         assert_same(k.numpy(), oracle.gaussian(sigma), "gaussian")
         got = mc.adcensus.mean2d(med, k.cuda(), t)
@@ -235,6 +235,17 @@ def test_mismatch_all_outliers(mc, oracle):
     outl = np.full((H, W), 2, np.float32)
     got = mc.adcensus.interpolate_mismatch(dev(d0)[None, None], dev(outl)[None, None])
     assert_same(host(got), oracle.interpolate_mismatch(d0, outl), "mismatch all-2")
+
+
+@pytest.mark.parametrize("H,W,p_mis", [(37, 53, 0.9), (64, 130, 0.97), (5, 300, 0.8), (201, 7, 0.95), (90, 121, 0.5)])
+def test_mismatch_long_walks(mc, oracle, H, W, p_mis):
+    """Mostly-mismatch marks: the 16 rays walk far, through the half-pixel rounding on both sides of zero and out of every
+    image edge (the kernel walks in integer half pixels; the oracle accumulates floats and rounds like the reference)."""
+    rng = np.random.default_rng(H * 1000 + W)
+    d0 = rng.integers(0, 60, (H, W)).astype(np.float32) + rng.integers(0, 4, (H, W)).astype(np.float32) * 0.25
+    outl = np.where(rng.random((H, W)) < p_mis, 2, rng.integers(0, 2, (H, W))).astype(np.float32)
+    got = mc.adcensus.interpolate_mismatch(dev(d0)[None, None], dev(outl)[None, None])
+    assert_same(host(got), oracle.interpolate_mismatch(d0, outl), "mismatch long walks")
 
 
 def test_normalize_fix_border(mc, oracle):
