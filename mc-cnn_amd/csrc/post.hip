@@ -348,6 +348,9 @@ template <int K> __device__ __forceinline__ void ray_rank_step(float v, int inb,
 // xx is an exact multiple of 0.5 and round(xx) (half away from zero) = (X2 + 1 + (X2 >> 31)) >> 1 for X2 = 2 xx -- the same pixels,
 // without the float rounding sequence.  The mark is fetched through a buffer whose range check answers 0 ("not a mismatch")
 // for a position outside the image, so the loop has one exit test and no nested regions.
+#ifndef MC_MIS_NU
+#define MC_MIS_NU 4
+#endif
 __global__ void __launch_bounds__(256) interp_mis_rays_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
                                                               float *__restrict__ out, int size, int H, int W)
 {
@@ -367,19 +370,33 @@ __global__ void __launch_bounds__(256) interp_mis_rays_kernel(const float *__res
 	const int x = id % W, y = id / W;
 	const int sx = hx[ray], sy = hy[ray];
 	const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)outlier, 0, size * 4, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)d0, 0, size * 4, 0x00020000);
 	int X2 = 2 * x, Y2 = 2 * y;
-	int xi = x, yi = y;
-	bool inb = true;                 // the start pixel is a mismatch: the first test passes by construction
-	for (;;) {
-		X2 += sx;
-		Y2 += sy;
-		xi = (X2 + 1 + (X2 >> 31)) >> 1;
-		yi = (Y2 + 1 + (Y2 >> 31)) >> 1;
-		inb = (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W;
-		const unsigned o = __builtin_amdgcn_raw_buffer_load_b32(ro, inb ? (__umul24((unsigned)yi, (unsigned)W) + (unsigned)xi) * 4u : 0x80000000u, 0, 0);   // H*W < 2^27
-		if (__uint_as_float(o) != 2.0f) break;
+	// The path does not depend on what it finds: the marks of the next MC_MIS_NU positions are requested together and tested in
+	// order, so a step costs a fraction of a memory round trip (the start pixel is a mismatch: the walk begins one step out).
+	constexpr unsigned OOB = 0x80000000u;
+	unsigned stop = OOB;             // byte offset of the pixel the ray stops at, OOB if it left the image
+	for (bool go = true; go;) {
+		unsigned off[MC_MIS_NU], o[MC_MIS_NU];
+#pragma unroll
+		for (int i = 0; i < MC_MIS_NU; ++i) {
+			X2 += sx;
+			Y2 += sy;
+			const int xi = (X2 + 1 + (X2 >> 31)) >> 1;
+			const int yi = (Y2 + 1 + (Y2 >> 31)) >> 1;
+			const bool in = (unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W;
+			off[i] = in ? (__umul24((unsigned)yi, (unsigned)W) + (unsigned)xi) * 4u : OOB;   // H*W < 2^27
+			o[i] = __builtin_amdgcn_raw_buffer_load_b32(ro, off[i], 0, 0);
+		}
+#pragma unroll
+		for (int i = MC_MIS_NU - 1; i >= 0; --i) {       // the first position whose mark is not 2 wins
+			const bool hit = __uint_as_float(o[i]) != 2.0f;
+			stop = hit ? off[i] : stop;
+			go = hit ? false : go;
+		}
 	}
-	const float v = inb ? d0[yi * W + xi] : 0.0f;
+	const int inb = stop != OOB ? 1 : 0;
+	const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, stop, 0, 0));   // 0 outside
 	// all 16 lanes of this pixel are here (mis is uniform over the row of 16)
 	int less = 0, eq = inb;
 	ray_rank_step<1>(v, inb, less, eq); ray_rank_step<2>(v, inb, less, eq); ray_rank_step<3>(v, inb, less, eq);
