@@ -100,6 +100,37 @@ struct StepData {
 	unsigned a0;   // class of the reference pixel's edge (same value in every lane)
 };
 
+
+// v_min_f32 / v_min3_f32 as written: fminf() through the compiler canonicalises every operand it cannot prove quiet (a v_max x, x
+// each) -- no signalling NaN can reach a minimum here: the operands are results of additions, of other minima, or +INF.
+__device__ __forceinline__ float vmin2(float a, float b)
+{
+	float r;
+	asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c)
+{
+	float r;
+	asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+// min over the 64 lanes of quiet values, wave-uniform (mc::wave_min with the DPP folded into the minimum: 13 instructions
+// instead of 31 -- a sweep runs one or two waves per SIMD, where every instruction is ~8 cycles of the recurrence)
+__device__ __forceinline__ float wave_min_q(float v)
+{
+	float r;
+	asm volatile("s_nop 1\n\tv_min_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_min_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_min_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_min_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_min_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_min_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+	             "s_nop 0\n\tv_readlane_b32 %0, %1, 63"
+	             : "=s"(r), "+v"(v));
+	return r;
+}
+
 // One pixel's run of costs as a raw buffer: base = vol + pix*ds, num_records = the run's bytes, so that
 // lanes whose disparities lie beyond the run are dropped (stores) / zero-filled (loads) by the hardware
 // range check instead of by exec-masked branches -- the steady-state loop stays straight-line code and
@@ -120,7 +151,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pixel_rsrc(const float *base, 
 //   reference, ((0 + L_0) + L_1) + L_2) + L_3, is restored by MODE 3.
 // U = steps kept in flight per wave (register ring): the scan is a strict recurrence, so memory latency is
 //   covered by prefetch depth, not by occupancy.
-template <int DIRN, int VPL, int MODE, bool ARGMIN, bool VEC, int U, bool DUAL>
+template <int DIRN, int VPL, int MODE, bool ARGMIN, bool VEC, int U, bool DUAL, bool FAR>
 __global__ void __launch_bounds__(256) sgm_pass_kernel(const SgmPassArgs A)
 {
 	constexpr int NACC = MODE == 0 ? 0 : (MODE == 3 ? 2 : 1);
@@ -170,52 +201,81 @@ __global__ void __launch_bounds__(256) sgm_pass_kernel(const SgmPassArgs A)
 	const float P1lo = A.P1[0], P2lo = A.P2[0], P1alo = A.P1a[0];
 	const float P1hi = A.P1[2], P2hi = A.P2[2], P1ahi = A.P1a[2];
 
-	auto load_run = [&](float (&dst)[VPL], const float *base, int64_t pix) {
-		const __amdgpu_buffer_rsrc_t r = pixel_rsrc(base, pix * ds, run_bytes);
+	// Addressing.  A line's pixels are pix0 + s*dp (dp = +-1 or +-W).  FAR = false (every line spans < 2 GiB of a volume): one
+	// descriptor per volume for the whole sweep -- base = the line's lowest-addressed pixel, num_records = the line's span --
+	// and a step costs one scalar multiply-add per array: rel(s)*ds*4 goes into the instruction's scalar offset (which the
+	// range check includes on this hardware: a per-pixel num_records cannot be combined with it).  The lanes beyond a pixel's
+	// run carry an out-of-range offset instead (loop-invariant), so their loads still return 0 and their stores are dropped.
+	// FAR = true rebuilds a 64-bit base per pixel (13 scalar instructions per array and step, a third of the loop).
+	const int last = nsteps - 1;
+	const int pix0 = y0s * W + x0s, dp = sy * W + sx;
+	const int minpix = dp > 0 ? pix0 : pix0 + last * dp;
+	const unsigned c1v = (unsigned)(dp * ds * 4);                       // modular: c0v + s*c1v is the true offset in [0, 2^31)
+	const unsigned c0v = dp > 0 ? 0u : (unsigned)last * (unsigned)(-dp * ds * 4);
+	const unsigned span = (unsigned)last * (unsigned)((dp > 0 ? dp : -dp) * ds * 4) + (unsigned)run_bytes;
+	constexpr unsigned OOBV = 0x80000000u;                              // + any scalar offset < 2^31: beyond every span, no wrap
+	const __amdgpu_buffer_rsrc_t rC = pixel_rsrc(Cp, (int64_t)minpix * ds, FAR ? 0 : span);
+	const __amdgpu_buffer_rsrc_t rA = pixel_rsrc(NACC >= 1 ? Ain : Cp, (int64_t)minpix * ds, FAR ? 0 : span);
+	const __amdgpu_buffer_rsrc_t rA2 = pixel_rsrc(NACC >= 2 ? Ain2 : Cp, (int64_t)minpix * ds, FAR ? 0 : span);
+	const __amdgpu_buffer_rsrc_t rO = pixel_rsrc(Out, (int64_t)minpix * ds, FAR ? 0 : span);
+	const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void *)win, 0, H * Wm + 2 * WBIAS + 64, 0x00020000);
+	const int w0 = y0s * Wm + x0s, dw = sy * Wm + sx;
+	const __amdgpu_buffer_rsrc_t rCls = __builtin_amdgcn_make_buffer_rsrc((void *)cls0, 0, H * W, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rDisp = pixel_rsrc(ARGMIN ? Disp : Out, 0, H * W * 4);
+	unsigned lane_off[VEC ? VPL / 4 : VPL];                             // byte offset of this lane's values inside a run, or OOBV
+#pragma unroll
+	for (int q = 0; q < (VEC ? VPL / 4 : VPL); ++q) {
+		const unsigned b = (unsigned)(dbase + (VEC ? 4 * q : q)) * 4u;
+		lane_off[q] = (FAR || b < (unsigned)run_bytes) ? b : OOBV;
+	}
+	const unsigned lane0_off = lane == 0 ? 0u : OOBV;
+
+	// rs: the volume's descriptor (FAR: ignored), so: the pixel's scalar byte offset (FAR: ignored)
+	auto load_run = [&](float (&dst)[VPL], const float *base, const __amdgpu_buffer_rsrc_t &rs, unsigned so, int64_t pix) {
+		const __amdgpu_buffer_rsrc_t r = FAR ? pixel_rsrc(base, pix * ds, run_bytes) : rs;
+		const unsigned soff = FAR ? 0u : so;
 		if (VEC) {
 #pragma unroll
 			for (int q = 0; q < VPL / 4; ++q) {
-				const uint4v t = __builtin_amdgcn_raw_buffer_load_b128(r, (dbase + 4 * q) * 4, 0, MC_SGM_VOL_AUX);
+				const uint4v t = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off[q], soff, MC_SGM_VOL_AUX);
 				dst[4 * q + 0] = __uint_as_float(t.x); dst[4 * q + 1] = __uint_as_float(t.y);
 				dst[4 * q + 2] = __uint_as_float(t.z); dst[4 * q + 3] = __uint_as_float(t.w);
 			}
 		} else {
 #pragma unroll
-			for (int j = 0; j < VPL; ++j) dst[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (dbase + j) * 4, 0, 0));
+			for (int j = 0; j < VPL; ++j) dst[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off[j], soff, 0));
 		}
 	};
 
 	auto load_step = [&](StepData<VPL, NACC> &sd, int s) {
-		const int x = x0s + s * sx, y = y0s + s * sy;
-		const int64_t pix = (int64_t)y * W + x;
-		load_run(sd.c, Cp, pix);
-		if constexpr (NACC >= 1) load_run(sd.a, Ain, pix);
-		if constexpr (NACC >= 2) load_run(sd.a2, Ain2, pix);
+		const unsigned so = c0v + (unsigned)s * c1v;
+		const int64_t pix = FAR ? (int64_t)(y0s + s * sy) * W + (x0s + s * sx) : 0;
+		load_run(sd.c, Cp, rC, so, pix);
+		if constexpr (NACC >= 1) load_run(sd.a, Ain, rA, so, pix);
+		if constexpr (NACC >= 2) load_run(sd.a2, Ain2, rA2, so, pix);
 		unsigned pk = 0;
-		const __amdgpu_buffer_rsrc_t rw =
-		    __builtin_amdgcn_make_buffer_rsrc((void *)(win + (int64_t)y * Wm + x), 0, 2 * WBIAS + 64, 0x00020000);
+		const unsigned sw = (unsigned)(w0 + s * dw);
 #pragma unroll
-		for (int q = 0; q < VPL / 4; ++q) pk |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rw, woff + q * wq, 0, 0) << (8 * q);
+		for (int q = 0; q < VPL / 4; ++q) pk |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rW, woff + q * wq, sw, 0) << (8 * q);
 		sd.pk = pk;
-		const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(cls0 + pix), 0, 1, 0x00020000);
-		sd.a0 = __builtin_amdgcn_raw_buffer_load_b8(rc, 0, 0, 0);  // every lane reads the same byte
+		sd.a0 = __builtin_amdgcn_raw_buffer_load_b8(rCls, 0, (unsigned)(pix0 + s * dp), 0);  // every lane reads the same byte
 	};
 
 	auto store_step = [&](const float (&o)[VPL], int s) {
-		const int x = x0s + s * sx, y = y0s + s * sy;
-		const int64_t pix = (int64_t)y * W + x;
-		const __amdgpu_buffer_rsrc_t r = pixel_rsrc(Out, pix * ds, run_bytes);
+		const int64_t pix = FAR ? (int64_t)(y0s + s * sy) * W + (x0s + s * sx) : 0;
+		const __amdgpu_buffer_rsrc_t r = FAR ? pixel_rsrc(Out, pix * ds, run_bytes) : rO;
+		const unsigned soff = FAR ? 0u : c0v + (unsigned)s * c1v;
 		if (VEC) {
 #pragma unroll
 			for (int q = 0; q < VPL / 4; ++q) {
 				uint4v t;
 				t.x = __float_as_uint(o[4 * q + 0]); t.y = __float_as_uint(o[4 * q + 1]);
 				t.z = __float_as_uint(o[4 * q + 2]); t.w = __float_as_uint(o[4 * q + 3]);
-				__builtin_amdgcn_raw_buffer_store_b128(t, r, (dbase + 4 * q) * 4, 0, MC_SGM_VOL_AUX);
+				__builtin_amdgcn_raw_buffer_store_b128(t, r, lane_off[q], soff, MC_SGM_VOL_AUX);
 			}
 		} else {
 #pragma unroll
-			for (int j = 0; j < VPL; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[j]), r, (dbase + j) * 4, 0, 0);
+			for (int j = 0; j < VPL; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[j]), r, lane_off[j], soff, 0);
 		}
 		if (ARGMIN) {
 			// torch.min(vol,2) - 1 (main.lua:1049-1050) on the finished pixel: first strict
@@ -229,15 +289,14 @@ __global__ void __launch_bounds__(256) sgm_pass_kernel(const SgmPassArgs A)
 					bi = dbase + j;
 				}
 			}
-			const float mall = wave_min(best);
+			const float mall = wave_min_q(best);
 			const unsigned long long cand = __ballot(best == mall && best < INF);
 			// branch-free: ffs = 0 when no lane holds a finite minimum (all-NaN pixel -> index 0)
 			const int f = __builtin_ffsll((long long)cand);
 			const int got = __builtin_amdgcn_readlane(bi, (f - 1) & 63);
 			const int idx = f ? got : 0;
-			// one float per pixel: a 4-byte buffer at disp + pix, so only lane 0 is in range
-			const __amdgpu_buffer_rsrc_t rd = pixel_rsrc(Disp, pix, 4);
-			__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)idx), rd, lane * 4, 0, 0);
+			// one float per pixel, the pixel in the scalar offset: only lane 0 carries an in-range offset
+			__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)idx), rDisp, lane0_off, (unsigned)(pix0 + s * dp) * 4u, 0);
 		}
 	};
 
@@ -246,48 +305,70 @@ __global__ void __launch_bounds__(256) sgm_pass_kernel(const SgmPassArgs A)
 #pragma unroll
 	for (int j = 0; j < VPL; ++j) prev[j] = 0.0f;
 
+	// loop-invariant VALU operands, pinned in VGPRs (the compiler re-materialises them from SGPRs in every step otherwise)
+	float P1midv = P1mid, P2midv = P2mid, P1amidv = P1amid, INFv = INF;
+	asm volatile("" : "+v"(P1midv), "+v"(P2midv), "+v"(P1amidv), "+v"(INFv));
+	// MODE 0 writes 0 + L_r (out:zero() then +=, main.lua:1014), its concurrent second direction L_r itself: x + (+0) and x + (-0)
+	const float zadd = (DUAL && second) ? -0.0f : 0.0f;
+
 	auto process = [&](const StepData<VPL, NACC> &sd, int s) {
 		float val[VPL], o[VPL];
-		const bool first = s == 0;  // border branch, adcensus.cu:567-572: L_r = C
 		const int a0 = __builtin_amdgcn_readfirstlane((int)sd.a0);
 		const int amatch = a0 == 1 ? 3 : a0;
-		const float P1x = a0 == 0 ? P1lo : P1hi;
-		const float P2x = a0 == 0 ? P2lo : P2hi;
-		const float P1ax = a0 == 0 ? P1alo : P1ahi;
+		// scalar selects, as written: the compiler sends a select of two float SGPRs to the VALU (two moves and a v_cndmask each)
+		float P1x, P2x, P1ax = 0.0f;
+		if (DIRN >= 2)
+			asm("s_cmp_eq_u32 %3, 0\n\ts_cselect_b32 %0, %4, %5\n\ts_cselect_b32 %1, %6, %7\n\ts_cselect_b32 %2, %8, %9"
+			    : "=s"(P1x), "=s"(P2x), "=s"(P1ax)
+			    : "s"(a0), "s"(P1lo), "s"(P1hi), "s"(P2lo), "s"(P2hi), "s"(P1alo), "s"(P1ahi)
+			    : "scc");
+		else
+			asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_cselect_b32 %1, %5, %6"
+			    : "=s"(P1x), "=s"(P2x)
+			    : "s"(a0), "s"(P1lo), "s"(P1hi), "s"(P2lo), "s"(P2hi)
+			    : "scc");
 		const float down = lane_from_below(prev[VPL - 1], INF);
 		const float up = lane_from_above(prev[0], INF);
 #pragma unroll
 		for (int j = 0; j < VPL; ++j) {
 			const int b = (sd.pk >> (2 * j)) & 3;
 			const bool match = b == amatch;
-			const float P2 = match ? P2x : P2mid;
-			const float P1 = match ? P1x : P1mid;
-			const float P1a = match ? P1ax : P1amid;
+			const float P2 = match ? P2x : P2midv;
+			const float P1 = match ? P1x : P1midv;
+			const float P1a = match ? P1ax : P1amidv;
 			const float pm = j > 0 ? prev[j > 0 ? j - 1 : 0] : down;
 			const float pp = j < VPL - 1 ? prev[j < VPL - 1 ? j + 1 : 0] : up;
-			// adcensus.cu:607-613
-			float cost = fminf(prev[j], m + P2);
-			cost = fminf(cost, pm + (DIRN == 2 ? P1a : P1));
-			cost = fminf(cost, pp + (DIRN == 3 ? P1a : P1));
-			const float rec = (sd.c[j] + cost) - m;  // adcensus.cu:615
-			val[j] = first ? sd.c[j] : rec;
+			// adcensus.cu:607-613: min(min(min(prev, m + P2), pm + P1), pp + P1) as one v_min_f32 + v_min3_f32
+			float cost;
+			asm("v_min_f32 %0, %1, %2\n\tv_min3_f32 %0, %0, %3, %4"
+			    : "=&v"(cost)
+			    : "v"(prev[j]), "v"(m + P2), "v"(pm + (DIRN == 2 ? P1a : P1)), "v"(pp + (DIRN == 3 ? P1a : P1)));
+			val[j] = (sd.c[j] + cost) - m;  // adcensus.cu:615
 		}
-		float nm = INF;
+		if (s == 0) {   // border branch, adcensus.cu:567-572: L_r = C.  A uniform branch taken once per line, not VPL selects per step
+			asm volatile("; border step");
+#pragma unroll
+			for (int j = 0; j < VPL; ++j) val[j] = sd.c[j];
+		}
+		float q[VPL];
 #pragma unroll
 		for (int j = 0; j < VPL; ++j) {
-			if (MODE == 0) o[j] = (DUAL && second) ? val[j] : 0.0f + val[j];
+			if (MODE == 0) o[j] = val[j] + zadd;
 			else if (MODE == 1) o[j] = sd.a[j] + val[j];
 			else if (MODE == 2) o[j] = (sd.a[j] + val[j]) * 0.25f;
 			else o[j] = (sd.a[j] + sd.a2[j]) + val[j];
-			prev[j] = (dbase + j < D) ? fminf(val[j], INF) : INF;  // NaN -> +INF: fminf semantics of the recurrence
-			nm = fminf(nm, prev[j]);
+			q[j] = vmin2(val[j], INFv);                       // NaN -> +INF: fminf semantics of the recurrence
 		}
-		m = wave_min(nm);
+#pragma unroll
+		for (int j = 0; j < VPL; ++j) prev[j] = (dbase + j < D) ? q[j] : INFv;
+		float nm = vmin3(prev[0], prev[1], prev[2]);
+#pragma unroll
+		for (int j = 3; j < VPL; j += 2) nm = j + 1 < VPL ? vmin3(nm, prev[j], prev[j + 1]) : vmin2(nm, prev[j]);
+		m = wave_min_q(nm);
 		store_step(o, s);
 	};
 
 	StepData<VPL, NACC> ring[U];
-	const int last = nsteps - 1;
 #pragma unroll
 	for (int u = 0; u < U; ++u) load_step(ring[u], u < last ? u : last);
 
@@ -353,14 +434,22 @@ static void launch_pass(const SgmPassArgs &A, bool vec, hipStream_t st)
 #endif
 	const int U = DIRN == 2 ? 16 : (DIRN == 3 ? MC_SGM_U_UP : MC_SGM_U_H);
 #define MC_SGM_GO(VPL_, VEC_, U_) \
-	hipLaunchKernelGGL((sgm_pass_kernel<DIRN, VPL_, MODE, ARGMIN, VEC_, U_, DUAL>), grid, block, 0, st, A)
-	if (A.D <= 256) {
+	hipLaunchKernelGGL((sgm_pass_kernel<DIRN, VPL_, MODE, ARGMIN, VEC_, U_, DUAL, false>), grid, block, 0, st, A)
+#define MC_SGM_GO_FAR(VPL_, VEC_, U_) \
+	hipLaunchKernelGGL((sgm_pass_kernel<DIRN, VPL_, MODE, ARGMIN, VEC_, U_, DUAL, true>), grid, block, 0, st, A)
+	// a volume of 2 GiB or more: 64-bit pixel addresses in every step (one prefetch depth only)
+	const bool far = (int64_t)A.H * A.W * A.ds * 4 >= ((int64_t)1 << 31);
+	if (far) {
+		if (A.D <= 256) { if (vec) MC_SGM_GO_FAR(4, true, 4); else MC_SGM_GO_FAR(4, false, 4); }
+		else { if (vec) MC_SGM_GO_FAR(8, true, 4); else MC_SGM_GO_FAR(8, false, 2); }
+	} else if (A.D <= 256) {
 		if (vec) { if (U == 16) MC_SGM_GO(4, true, 16); else if (U == 8) MC_SGM_GO(4, true, 8); else MC_SGM_GO(4, true, 4); }
 		else MC_SGM_GO(4, false, 4);
 	} else {
 		if (vec) { if (U >= 8) MC_SGM_GO(8, true, 8); else MC_SGM_GO(8, true, 4); }
 		else MC_SGM_GO(8, false, 2);
 	}
+#undef MC_SGM_GO_FAR
 #undef MC_SGM_GO
 }
 
@@ -373,6 +462,8 @@ int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2
                const int direction[2], int nvol, int H, int W, int D, int ds, const void *maps, float pi1, float pi2,
                float alpha1, float q1, float q2, bool fused, hipStream_t st)
 {
+	// 32-bit pixel indices and line strides in the sweeps (a volume may still exceed 4 GiB: the FAR instances)
+	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) && (int64_t)W * ds * 4 < ((int64_t)1 << 31), "sgm: image %dx%d (pixel stride %d) exceeds the sweeps' 32-bit line arithmetic", H, W, ds);
 	SgmPassArgs A;
 	for (int v = 0; v < 2; ++v) {
 		const int k = v < nvol ? v : 0;
