@@ -140,6 +140,11 @@ int mc_sgm2(const float *x0, const float *x1, const float *in_hwd, float *out_hw
             float pi1, float pi2, float tau_so, float alpha1, float sgm_q1, float sgm_q2,
             int direction, void *stream);
 
+/* Debug aid for mc_sgm2's contract (no reference counterpart): *count (a device word, zeroed by the call) receives the
+ * number of pixels of in_hwd whose cost vector violates it -- d = 0 not finite, or a non-NaN value behind a NaN.  The
+ * Python mirror calls it before every sgm2 when MC_CHECK_CONTRACTS=1 is set in the environment (and synchronises). */
+int mc_sgm2_contract_violations(const float *in_hwd, int H, int W, int D, unsigned *count, void *stream);
+
 /* vol:transpose(2,3):transpose(3,4):clone(), main.lua:1008: (D,H,W) -> (H,W,D). */
 int mc_dhw_to_hwd(const float *in, float *out, int D, int H, int W, void *stream);
 /* vol:copy(out:transpose(3,4):transpose(2,3)):div(4), main.lua:1019-1020:

@@ -17,7 +17,7 @@ SYMBOLS = [
     "mc_interpolate_mismatch", "mc_subpixel_enchancement", "mc_median2d", "mc_mean2d", "mc_gaussian_host",
     "mc_normalize_forward", "mc_predict_workspace_bytes", "mc_predict", "mc_predict_timed",
     "mc_cbca_plan_bytes", "mc_cbca_ws_cfg", "mc_transpose_cfg",
-    "mc_read_png16", "mc_write_png16", "mc_write_pfm",
+    "mc_read_png16", "mc_write_png16", "mc_write_pfm", "mc_sgm2_contract_violations",
 ]
 
 
@@ -57,6 +57,7 @@ def _load():
         "mc_cbca_ws": [vp, vp, vp, vp, i, i, i, i, vp, sz, vp],
         "mc_sgm2_tmp_bytes": [i, i, i],
         "mc_sgm2": [vp, vp, vp, vp, vp, sz, i, i, i, f, f, f, f, f, f, i, vp],
+        "mc_sgm2_contract_violations": [vp, i, i, i, vp, vp],
         "mc_dhw_to_hwd": [vp, vp, i, i, i, vp],
         "mc_hwd_to_dhw": [vp, vp, i, i, i, f, vp],
         "mc_scale": [vp, vp, i64, f, vp],

@@ -8,6 +8,8 @@ the SAME tensors (e.g. cross: H,W from `out`, adcensus.cu:336-337) to the C ABI
 must be contiguous fp32 on the GPU; unlike it, that is checked.  A non-zero return
 code raises McError where the reference raises a Lua error.
 """
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -132,6 +134,17 @@ def cbca_reference_shaped(x0c, x1c, vol_in, vol_out, direction):
     check(lib.mc_cbca(_p(x0c), _p(x1c), _p(vol_in), _p(vol_out), D, H, W, int(direction), _stream()), "cbca")
 
 
+def sgm2_contract_violations(input):
+    """Debug aid (no reference counterpart): the number of pixels of an (1,H,W,D) volume that violate sgm2's contract --
+    d = 0 not finite, or a value that is not NaN behind a NaN (the reference's `<`-tree minimum and this library's
+    fminf-recurrence agree on everything else).  Synchronises."""
+    _chk(input)
+    H, W, D = input.shape[-3:]
+    cnt = torch.zeros(1, dtype=torch.int32, device=input.device)
+    check(lib.mc_sgm2_contract_violations(_p(input), H, W, D, cnt.data_ptr(), _stream()), "sgm2_contract_violations")
+    return int(cnt.item())
+
+
 def sgm2(x0, x1, input, output, tmp, pi1, pi2, tau_so, alpha1, sgm_q1, sgm_q2, direction):
     """adcensus.sgm2(...) -- adcensus.cu:620-697.  input/output are (1,H,W,D); the four
     directional costs are added to `output`.  `tmp` is the reference's (W,D) line-state
@@ -140,6 +153,10 @@ def sgm2(x0, x1, input, output, tmp, pi1, pi2, tau_so, alpha1, sgm_q1, sgm_q2, d
     otherwise a cached per-shape scratch is used."""
     _chk(x0, x1, input, output)
     H, W, D = input.shape[-3:]
+    if os.environ.get("MC_CHECK_CONTRACTS") == "1":   # host-side debug switch; the library itself reads no environment
+        bad = sgm2_contract_violations(input)
+        if bad:
+            raise ValueError("sgm2: %d pixels of the input volume violate the contract (d = 0 finite, NaNs form a tail in d)" % bad)
     need = lib.mc_sgm2_tmp_bytes(H, W, D)
     if isinstance(tmp, torch.Tensor) and tmp.is_cuda and tmp.is_contiguous() and tmp.numel() * tmp.element_size() >= need:
         scratch = tmp

@@ -55,6 +55,7 @@ int fc_stack(const float *featL, const float *featR, int C, int H, int W, int D,
              const float *const *biases, int n_layers, float *volL, float *volR, void *workspace, hipStream_t st);
 size_t sgm_maps_bytes(int H, int W);
 int sgm_prep(const float *x0, const float *x1, void *maps, int H, int W, float tau_so, hipStream_t st);
+int sgm_contract_violations(const float *vol, int H, int W, int D, unsigned *count, hipStream_t st);
 int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2], float *const disp[2],
                const int direction[2], int nvol, int H, int W, int D, int ds, const void *maps, float pi1, float pi2,
                float alpha1, float q1, float q2, bool fused, hipStream_t st);
@@ -700,6 +701,13 @@ int mc_transpose_cfg(const float *in, float *out, int64_t rows, int64_t cols, in
 	return transpose(in, out, rows, cols, ldin, ldout, scale_, as_stream(stream), nt);
 }
 
+
+int mc_sgm2_contract_violations(const float *in_hwd, int H, int W, int D, unsigned *count, void *stream)
+{
+	MC_REQUIRE(in_hwd && count, "mc_sgm2_contract_violations: null pointer");
+	MC_REQUIRE(dims_ok(D, H, W), "mc_sgm2_contract_violations: bad dims");
+	return sgm_contract_violations(in_hwd, H, W, D, count, as_stream(stream));
+}
 
 size_t mc_sgm2_tmp_bytes(int H, int W, int D)
 {

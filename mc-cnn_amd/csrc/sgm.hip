@@ -395,6 +395,37 @@ __global__ void __launch_bounds__(256) sgm_pass_kernel(const SgmPassArgs A)
 
 // ---------------------------------------------------------------------------
 
+// mc_sgm2's contract on a caller's volume (debug aid): NaNs form a tail in d and d = 0 is finite
+__global__ void __launch_bounds__(256) sgm_contract_kernel(const float *__restrict__ vol, int64_t pixels, int D, unsigned *__restrict__ count)
+{
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool bad = false;
+	if (p < pixels) {
+		const float *v = vol + p * D;
+		bad = !(fabsf(v[0]) < __builtin_inff());
+		bool seen_nan = false;
+		for (int d = 0; d < D; ++d) {
+			const bool isn = v[d] != v[d];
+			bad = bad || (seen_nan && !isn);
+			seen_nan = seen_nan || isn;
+		}
+	}
+	const unsigned long long b = __ballot(bad);
+	if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned)__builtin_popcountll(b));
+}
+
+int sgm_contract_violations(const float *vol, int H, int W, int D, unsigned *count, hipStream_t st)
+{
+	const int64_t pixels = (int64_t)H * W;
+	hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned), st);
+	if (e != hipSuccess) {
+		set_error("mc_sgm2_contract_violations: hipMemsetAsync: %s", hipGetErrorString(e));
+		return (int)e;
+	}
+	hipLaunchKernelGGL(sgm_contract_kernel, dim3(cdiv(pixels, 256)), dim3(256), 0, st, vol, pixels, D, count);
+	return check_launch("sgm_contract");
+}
+
 size_t sgm_maps_bytes(int H, int W)
 {
 	const size_t Wm = (size_t)W + 2 * SGM_PADW;

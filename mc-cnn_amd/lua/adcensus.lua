@@ -43,6 +43,7 @@ size_t mc_sgm2_tmp_bytes(int H, int W, int D);
 int mc_sgm2(const float *x0, const float *x1, const float *in_hwd, float *out_hwd, void *tmp, size_t tmp_bytes,
             int H, int W, int D, float pi1, float pi2, float tau_so, float alpha1, float sgm_q1, float sgm_q2,
             int direction, void *stream);
+int mc_sgm2_contract_violations(const float *in_hwd, int H, int W, int D, unsigned *count, void *stream);
 int mc_spatial_argmin(const float *vol, float *out, int D, int H, int W, void *stream);
 int mc_outlier_detection(const float *d0, const float *d1, float *outlier, int H, int W, int disp_max, void *stream);
 int mc_interpolate_occlusion(const float *d0, const float *outlier, float *out, int H, int W, void *stream);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# counters of the tile kernel's plan-writing and plan-reading passes: bash scripts/gpu_pmc_plan.sh <case> [passes]   (round 4: also used on the rolling form, history at 4a1c: profiles/r04_cbca_roll_pmc.txt)
+# counters of the tile kernel's plan-writing and plan-reading passes: bash scripts/gpu_pmc_plan.sh <case> [passes]   (round 4: also used on the rolling form, history at b8c043d: profiles/r04_cbca_roll_pmc.txt)
 ulimit -c 0
 CASE=${1:-14natural}; NP=${2:-2}
 O=$GRAFT_REPO_ROOT/gpurun_out/pmcp_$CASE; mkdir -p $O

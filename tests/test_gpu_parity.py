@@ -248,6 +248,26 @@ def test_mismatch_long_walks(mc, oracle, H, W, p_mis):
     assert_same(host(got), oracle.interpolate_mismatch(d0, outl), "mismatch long walks")
 
 
+def test_sgm2_contract_check(mc, monkeypatch):
+    """mc_sgm2's documented input contract, checkable: volumes the pipeline produces pass; a NaN before a number, or a
+    non-finite d = 0, is counted -- and the Python mirror refuses such a volume under MC_CHECK_CONTRACTS=1."""
+    H, W, D = 9, 21, 12
+    vl, _ = raw_volumes(D, H, W, seed=3)                       # (D,H,W) with the NaN triangle of a left volume
+    hwd = np.ascontiguousarray(vl.transpose(1, 2, 0))[None]
+    assert mc.adcensus.sgm2_contract_violations(dev(hwd)) == 0
+    bad = hwd.copy()
+    bad[0, 2, 5, 3] = np.nan                                   # a hole: finite values behind it
+    bad[0, 4, 7, 0] = np.inf                                   # d = 0 not finite
+    bad[0, 4, 8, 0] = np.nan
+    assert mc.adcensus.sgm2_contract_violations(dev(bad)) == 3
+    x = torch.zeros((1, 1, H, W), device="cuda")
+    out = torch.zeros_like(dev(bad))
+    monkeypatch.setenv("MC_CHECK_CONTRACTS", "1")
+    with pytest.raises(ValueError, match="violate the contract"):
+        mc.adcensus.sgm2(x, x, dev(bad), out, torch.empty(1, device="cuda"), 1.0, 8.0, 0.1, 2.0, 3.0, 2.0, -1)
+    mc.adcensus.sgm2(x, x, dev(hwd), out, torch.empty(1, device="cuda"), 1.0, 8.0, 0.1, 2.0, 3.0, 2.0, -1)
+
+
 def test_normalize_fix_border(mc, oracle):
     rng = np.random.default_rng(9)
     x = rng.standard_normal((2, 16, 11, 23)).astype(np.float32)
