@@ -122,6 +122,29 @@ def test_sgm2(ref, mc, oracle, H, W, D, prm, direction):
     same(host(g), host(r), "hip sgm2 vs reference")
 
 
+def test_sgm2_volume_of_two_gib(ref, mc):
+    """A volume of 2 GiB or more takes the sweeps' 64-bit-address instances (sgm.hip: FAR), which no other shape reaches: sgm2 at
+    560 x 3840 x 256 (2.2 GB) against the reference's kernels on the same device tensors, compared on the device."""
+    H, W, D = 560, 3840, 256
+    assert H * W * D * 4 >= 1 << 31
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x0 = torch.rand((1, 1, H, W), device="cuda", generator=g)
+    x1 = torch.rand((1, 1, H, W), device="cuda", generator=g)
+    vol = torch.rand((1, H, W, D), device="cuda", generator=g)
+    d = torch.arange(D, device="cuda")[None, None, None, :]
+    xx = torch.arange(W, device="cuda")[None, None, :, None]
+    vol.masked_fill_(d > xx, float("nan"))                    # the NaN triangle of a left volume
+    prm = (1.3, 13.9, 0.13, 2.75, 4.5, 2.0)
+    r = torch.zeros_like(vol)
+    tmp = torch.empty((W, D), device="cuda")
+    ref.call("sgm2", x0[0], x1[0], vol, r, tmp, *prm, -1)
+    got = torch.zeros_like(vol)
+    mc.adcensus.sgm2(x0[0, 0], x1[0, 0], vol, got, None, *prm, -1)
+    torch.cuda.synchronize()
+    same_dev = bool(((got.view(torch.int32) == r.view(torch.int32)) | (torch.isnan(got) & torch.isnan(r))).all().item())
+    assert same_dev, "hip sgm2 (2.2 GB volume) differs from the reference's kernels"
+
+
 @pytest.mark.parametrize("H,W,D", SHAPES[:4])
 def test_spatial_argmin(ref, mc, oracle, H, W, D):
     vl, _ = raw_volumes(D, H, W, seed=31)
