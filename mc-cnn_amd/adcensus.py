@@ -110,14 +110,27 @@ def cbca_cfg(x0c, x1c, vol_in, vol_out, direction, rb=0, nt=-1, d0=0, nd=0, form
     a 6 / 7 call must follow a 4 / 5 call on the same arms, shape and direction; 8 / 9 the lean kernel of textured pairs:
     8 first lists the outputs whose support is not the minimal 3 x 3 behind the packed lengths, 9 reads that list -- the strip
     kernel takes over if the list is not this problem's or did not fit; rb = rows per wave (2 / 4 / 8), d0 = launch variant, nd = slots
-    the list may hold)
+    the list may hold; 10 / 11 TWO aggregation passes in one launch (vol_out = the volume after the second): 10 writes the list of that
+    kernel's wave geometry first, 11 reads it; rb = rows per wave (4 / 8 / 12), d0 > 0 = the list's cost limit in values per voxel)
     -- instead of derived from the problem."""
     _chk(x0c, x1c, vol_in, vol_out)
     D, H, W = vol_out.shape[-3:]
     need = lib.mc_cbca_scratch_bytes(H, W) + (lib.mc_cbca_plan_bytes(D, H, W) if form >= 4 else 0)
+    if form >= 10:
+        need += 512 + 4 * D * H * W
     scratch = _scratch_for(vol_out.device, need)
     check(lib.mc_cbca_ws_cfg(_p(x0c), _p(x1c), _p(vol_in), _p(vol_out), D, H, W, int(direction), scratch.data_ptr(), need,
                              int(rb), int(nt), int(d0), int(nd), int(form), _stream()), "cbca_cfg")
+
+
+def cbca_cfg_list_header(device, D, H, W, form):
+    """Test helper: the first eight words of the list the last cbca_cfg(form = 8 .. 11) call of this shape left behind the packed lengths
+    -- (count, overflow, D, H, W, direction + 1, magic, rows per wave [+ 0x100 two-pass geometry]); overflow != 0 = the list was declared
+    unusable and the strip kernel took the passes."""
+    cs = lib.mc_cbca_scratch_bytes(H, W)
+    need = cs + lib.mc_cbca_plan_bytes(D, H, W) + ((512 + 4 * D * H * W) if form >= 10 else 0)
+    off = (cs + 255) // 256 * 256
+    return _scratch_for(device, need)[off:off + 32].view(torch.int32).cpu().tolist()
 
 
 def transpose_cfg(inp, out, rows, cols, ldin, ldout, scale=1.0, nt=-1):

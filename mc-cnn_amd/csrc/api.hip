@@ -42,9 +42,11 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 size_t cbca_plan_bytes(int D, int H, int W);
 int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int route,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
-bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes);
+bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes, bool two_pass = false);
 int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, int rb, int cap_limit,
-                  hipStream_t st);
+                  hipStream_t st, bool two_pass = false, float cost_limit = 0);
+int cbca_lean2x(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
+                int route, hipStream_t st, const CbcaCfg &cfg);
 int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
               int route, hipStream_t st, const CbcaCfg &cfg);
 size_t conv3x3_workspace_bytes(int Cin, int Cout);
@@ -145,8 +147,10 @@ static int cbca_by_arms(const void *packed, const float *vin, float *vout, int D
 		if (rc) return rc;
 	}
 	if (cfg.lean) {   // textures (route CR_STRIP) out of the pair's list: the lean + list kernels, the strip kernel only if the list is unusable
-		rc = cbca_lean(packed, cfg.plan, cfg.plan_bytes, vin, vout, D, H, W, direction, CR_STRIP, st, cfg);
-		if (rc) return rc;
+		if (!cfg.lean_two_pass) {   // (two passes per launch: cbca_lean2x, launched by the caller for a pair of passes)
+			rc = cbca_lean(packed, cfg.plan, cfg.plan_bytes, vin, vout, D, H, W, direction, CR_STRIP, st, cfg);
+			if (rc) return rc;
+		}
 		return cbca_strips(packed, vin, vout, D, H, W, direction, CR_STRIP_IF_NO_LIST, st, cfg);
 	}
 	return cbca_strips(packed, vin, vout, D, H, W, direction, max_arm > 13 ? CR_STRIP_OR_TILE13 : CR_STRIP, st, cfg);
@@ -278,6 +282,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	float *gk = (float *)w; w += pl.gk;
 	void *cplan[2] = {pl.cplan ? (void *)w : nullptr, (pl.cplan && pl.nplan > 1) ? (void *)(w + pl.cplan) : nullptr};
 	int cplan_passes[2] = {0, 0};   // aggregation passes so far: the first one writes the plan, the others read it
+	bool cplan_listed[2] = {false, false};   // ... the texture route's list has been written
 	const int Dp = pl.Dp;
 	int rc;
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
@@ -309,28 +314,43 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	// direction +1 (the right volume) is skipped where the reference skips it: dataset mb outside `-a predict`
 	// (mb_directions, main.lua:953-955) -- only when nothing of it is asked for
 	const int nvol = (p->left_only && !p->lr_check && !volR_out && !dispR0_out) ? 1 : 2;
-	// n CBCA iterations on the (D,H,W) volumes, ping-pong between the two buffers of each side (instead of vol:copy(tmp))
+	// n CBCA iterations on the (D,H,W) volumes, ping-pong between the two buffers of each side (instead of vol:copy(tmp)).
+	// Where the pair's route may be the texture one (cfg.lean), the iterations go in PAIRS: cbca_lean2x runs two passes in one launch
+	// (cur -> dst) out of a list written once per pair and direction; the kernels of the other routes -- which one runs is decided on
+	// the device by the route word, the others stand down at their first instruction -- take the same two passes through the SGM's
+	// scratch volume (cur -> bufC -> dst), so that every route ends in the same buffer.  An odd last iteration is a single pass.
 	auto cbca_iterations = [&](int n) -> int {
 		const bool packed_ok = cbca_cap <= 254 && packed_dims_ok(H, W);  // packed lengths saturate at 255
-		for (int i = 0; i < n; ++i) {
-			for (int v = 0; v < nvol; ++v) {
+		for (int v = 0; v < nvol; ++v) {
+			for (int i = 0; i < n;) {
 				float *dst = other(v);
 				CbcaCfg cfg;
 				cfg.plan = cplan[v];
 				cfg.plan_bytes = pl.cplan;
-				const bool first = cplan_passes[v] == 0;
-				cfg.plan_mode = cplan[v] ? (cplan_passes[v]++ == 0 ? 1 : 2) : 0;
 				// the plan area serves whichever kernel the pair's route word picks: the tile kernel's plan (written by its first
-				// pass) or, on textures, the list of outputs whose support is not the minimal 3 x 3 (written here, before the first pass)
-				cfg.lean = packed_ok && cplan[v] && cbca_cap > 4 && cbca_cap <= 13 && cbca_lean_fits(D, H, W, pl.cplan);
-				if (cfg.lean && first) {
-					const int rc1 = cbca_classify(packed, cplan[v], pl.cplan, D, H, W, direction[v], CR_STRIP, 0, 0, st);
+				// pass) or, on textures, the list of outputs whose support is not the minimal 3 x 3 (written here, before the first pair)
+				const bool two = packed_ok && cplan[v] && cbca_cap > 4 && cbca_cap <= 13 && i + 1 < n && cbca_lean_fits(D, H, W, pl.cplan, true);
+				cfg.lean = cfg.lean_two_pass = two;   // (a single pass: the strip kernel serves the texture route itself)
+				if (two && !cplan_listed[v]) {
+					const int rc1 = cbca_classify(packed, cplan[v], pl.cplan, D, H, W, direction[v], CR_STRIP, 0, 0, st, true);
 					if (rc1) return rc1;
+					cplan_listed[v] = true;
 				}
-				const int rc2 = packed_ok ? cbca_by_arms(packed, cur[v], dst, D, H, W, direction[v], cbca_cap, st, cfg)
-				                          : cbca(x0c, x1c, cur[v], dst, D, H, W, direction[v], st);
-				if (rc2) return rc2;
+				float *mid = two ? bufC[v] : dst;
+				for (int half = 0; half < (two ? 2 : 1); ++half) {   // the routes that take one pass per launch
+					cfg.plan_mode = cplan[v] ? (cplan_passes[v]++ == 0 ? 1 : 2) : 0;
+					const float *src = half == 0 ? cur[v] : mid;
+					float *to = (two && half == 0) ? mid : dst;
+					const int rc2 = packed_ok ? cbca_by_arms(packed, src, to, D, H, W, direction[v], cbca_cap, st, cfg)
+					                          : cbca(x0c, x1c, src, to, D, H, W, direction[v], st);
+					if (rc2) return rc2;
+				}
+				if (two) {
+					const int rc3 = cbca_lean2x(packed, cplan[v], pl.cplan, cur[v], dst, D, H, W, direction[v], CR_STRIP, st, cfg);
+					if (rc3) return rc3;
+				}
 				cur[v] = dst;
+				i += two ? 2 : 1;
 			}
 		}
 		return 0;
@@ -643,13 +663,41 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 	           cbca_scratch_bytes(H, W));
 	MC_REQUIRE((uintptr_t)scratch % 4 == 0, "mc_cbca_ws_cfg: scratch must be 4-byte aligned");
 	MC_REQUIRE(packed_dims_ok(H, W), "mc_cbca_ws_cfg: image too large for the packed-length kernels (32-bit plane offsets, 24-bit row indices)");
-	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 9, "mc_cbca_ws_cfg: bad rb / nt / form");
+	MC_REQUIRE(rb >= 0 && rb <= 4096 && nt >= -1 && nt <= 1 && form >= 0 && form <= 11, "mc_cbca_ws_cfg: bad rb / nt / form");
 	MC_REQUIRE(d0 >= 0 && nd >= 0 && (form >= 8 || d0 + nd <= D), "mc_cbca_ws_cfg: planes [%d, %d) outside the volume", d0, d0 + nd);
 	hipStream_t st = as_stream(stream);
 	int rc = cbca_pack(x0c, x1c, scratch, H, W, st);
 	if (rc) return rc;
 	CbcaCfg cfg;
 	cfg.nt = nt; cfg.d0 = d0; cfg.nd = nd;
+	if (form >= 10) {   // TWO passes in one launch (cbca_lean2x): 10 writes the list of its wave geometry first, 11 reads it; vol_out = the volume after
+		// the second pass.  The strip kernel takes both passes (through a volume behind the list) if the list is not this problem's or did not fit.
+		const size_t off = align_up(cbca_scratch_bytes(H, W), 256), pb = align_up(cbca_plan_bytes(D, H, W), 256);
+		const size_t vb = (size_t)D * H * W * sizeof(float);
+		MC_REQUIRE(scratch_bytes >= off + pb + vb, "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu with the list and a volume", scratch_bytes, off + pb + vb);
+		MC_REQUIRE((uintptr_t)scratch % 16 == 0, "mc_cbca_ws_cfg: scratch must be 16-byte aligned for the list");
+		MC_REQUIRE(cbca_lean_fits(D, H, W, pb, true), "mc_cbca_ws_cfg: volume too large for 32-bit list entries");
+		cfg.plan = (char *)scratch + off;
+		cfg.plan_bytes = pb;
+		cfg.lean_rb = rb;
+		cfg.lean_two_pass = true;
+		cfg.d0 = 0; cfg.nd = nd;
+		float *mid = (float *)((char *)scratch + off + pb);
+		if (form == 10) {
+			rc = cbca_classify(scratch, cfg.plan, cfg.plan_bytes, D, H, W, direction, CR_NOT_DIRECT, rb, nd, st, true, (float)d0);   // (d0 > 0: the cost limit, in values per voxel)
+			if (rc) return rc;
+		}
+		rc = cbca_lean2x(scratch, cfg.plan, cfg.plan_bytes, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT, st, cfg);
+		if (rc) return rc;
+		cfg.nd = 0;
+		rc = cbca_strips(scratch, vol_in, mid, D, H, W, direction, CR_NOT_DIRECT_IF_NO_LIST, st, cfg);
+		if (rc) return rc;
+		rc = cbca_strips(scratch, mid, vol_out, D, H, W, direction, CR_NOT_DIRECT_IF_NO_LIST, st, cfg);
+		if (rc) return rc;
+		rc = cbca_if_overflow(x0c, x1c, scratch, vol_in, mid, D, H, W, direction, st);
+		if (rc) return rc;
+		return cbca_if_overflow(x0c, x1c, scratch, mid, vol_out, D, H, W, direction, st);
+	}
 	if (form >= 8) {   // lean kernel (textures): 8 lists the outputs whose support is not the minimal 3 x 3 behind the packed lengths first, 9 reads that list
 		const size_t off = align_up(cbca_scratch_bytes(H, W), 256), pb = cbca_plan_bytes(D, H, W);
 		MC_REQUIRE(scratch_bytes >= off + pb, "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu with the list", scratch_bytes, off + pb);

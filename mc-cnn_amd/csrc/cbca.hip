@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) cbca_direct_kernel(const float *__restric
 	out[id] = sum / (float)cnt;
 }
 
-int cbca_lean_rows(int D, int H, int W, int rb);   // cbca_lean.hip
+int cbca_lean_rows(int D, int H, int W, int rb, bool two_pass);   // cbca_lean.hip
 
 int cbca(const float *x0c, const float *x1c, const float *vin, float *vout, int D, int H, int W, int direction, hipStream_t st)
 {
@@ -456,7 +456,7 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	A.flags = route >= 0 ? cs.flag : nullptr;
 	A.route = route;
 	A.plan = cfg.plan;   // (CR_STRIP_IF_NO_LIST: the list header the launch looks at)
-	A.lean_rb = cbca_lean_rows(D, H, W, cfg.lean_rb);
+	A.lean_rb = cbca_lean_rows(D, H, W, cfg.lean_rb, cfg.lean_two_pass);
 	A.gx = (int)cdiv(W, CS_STEP);
 	// output rows per strip: 40 (5 % of halo rows) unless that leaves fewer than ~16 K waves -- at KITTI size (5 strips x
 	// 228 planes) 27 and 20 rows measured 5 % faster than 40, 53 rows 18 % slower

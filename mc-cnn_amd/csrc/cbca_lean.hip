@@ -28,12 +28,17 @@ struct LeanArgs {
 	uint32_t *hdr;               // list header (LH_*); behind it the wave table and the slots
 	uint32_t capd;               // slots per plane (the slots are allotted per plane)
 	uint32_t wtab_words;         // word offset of the wave table: per wave of the lean kernel {slot + 1 of its first entry, its entries}
+	float cost_limit;            // two-pass geometry: values recomputed per voxel, on average over a plane, beyond which the list is declared unusable
+	uint32_t cost_words;         // two-pass geometry: word offset of one float per wave -- what its second-pass entries cost beyond their own supports
 	uint32_t slots_words;        // word offset of the slots (16 bytes each)
 	uint32_t cap;                // slots the list can hold
 	int D, H, W, direction;
 	int rb, gx, gy;              // rows per wave, strips per row, row chunks
 	cb_u32 gx_rcp;               // ceil(2^32 / gx)
 	int order, gyb;              // wave order: 0 linear over the volume, 1 one band of gyb row chunks per XCD (blockIdx & 7), each swept linearly
+	int pitch, xoff, halo;       // a wave's 256 columns start at strip * pitch + xoff; the list covers halo rows above / below the wave's rows and its
+	                             // columns [halo, 256 - halo) (single pass: 256, 0, 0; two passes in one launch, cbca_lean2x_kernel: 252, -2, 1)
+	cb_u32 rbcode;               // header word LH_RB of a list of this geometry: rb, + 0x100 for the two-pass geometry
 	const uint32_t *flags;       // cbca_pack's flag words
 	int route;
 };
@@ -58,7 +63,7 @@ __device__ __forceinline__ bool lean_runs(const LeanArgs &A)
 	}
 	// (LH_COUNT, LH_OVERFLOW, LH_D, LH_H | LH_W, LH_DIR, LH_MAGIC, LH_RB)
 	const bool valid = (h1.z == LH_MAGIC_VALUE) & (h0.z == (cb_u32)A.D) & (h0.w == (cb_u32)A.H) & (h1.x == (cb_u32)A.W) &
-	                   (h1.y == (cb_u32)(A.direction + 1)) & (h1.w == (cb_u32)A.rb) & (h0.y == 0u);
+	                   (h1.y == (cb_u32)(A.direction + 1)) & (h1.w == A.rbcode) & (h0.y == 0u);
 	return gate & valid;
 }
 
@@ -83,7 +88,7 @@ __device__ __forceinline__ bool lean_wave(const LeanArgs &A, int wv, long long &
 	w = ((long long)d * A.gy + chunk) * A.gx + strip;
 	y0 = chunk * A.rb;
 	y1 = min(A.H, y0 + A.rb);
-	x0 = strip * 256;
+	x0 = strip * A.pitch + A.xoff;
 	return true;
 }
 
@@ -223,7 +228,7 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 	cb_u32 *__restrict__ buf = bufs[PASS ? wv : 0];
 	if (PASS == 1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // (the overflow word is the scan's)
 		A.hdr[LH_D] = (uint32_t)A.D; A.hdr[LH_H] = (uint32_t)A.H; A.hdr[LH_W] = (uint32_t)A.W;
-		A.hdr[LH_DIR] = (uint32_t)(A.direction + 1); A.hdr[LH_RB] = (uint32_t)A.rb; A.hdr[LH_MAGIC] = LH_MAGIC_VALUE;
+		A.hdr[LH_DIR] = (uint32_t)(A.direction + 1); A.hdr[LH_RB] = A.rbcode; A.hdr[LH_MAGIC] = LH_MAGIC_VALUE;
 	}
 	long long w;
 	int d, y0, y1, xb;
@@ -243,10 +248,10 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
 	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
-	cb_u32 want = 0;   // bit j: output column exists and has a partner (adcensus.cu:353)
+	cb_u32 want = 0;   // bit j: output column exists, has a partner (adcensus.cu:353) and is one this wave's list covers
 #pragma unroll
 	for (int j = 0; j < 4; ++j)
-		if (xs + j < W && xs + j + sh >= 0 && xs + j + sh < W) want |= 1u << j;
+		if (xs + j >= 0 && xs + j < W && xs + j + sh >= 0 && xs + j + sh < W && (unsigned)(4 * lane + j - A.halo) < (unsigned)(256 - 2 * A.halo)) want |= 1u << j;
 	// combined lengths of row r for this lane's four columns (rows outside the image: 0 = "not the unit arm")
 	auto fetch = [&](int r, cb_u32 (&m)[4]) {
 		const bool rok = r >= 0 && r < H;
@@ -258,6 +263,11 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 	};
 	int cnt = 0;         // PASS 0: the count; PASS 1: entries waiting in LDS
 	cb_u32 written = 0;  // PASS 1: entries already in their slots
+	// two-pass geometry: a second-pass entry (one among the wave's own outputs) sums FIRST-pass values; those outside the wave's tile
+	// (rows y0 - 1 .. y0 + rb, columns 1 .. 254) are recomputed from the input by cbca_lean2x_kernel, each at the price of its own
+	// support -- estimated here as (values outside the tile) x (values of the entry's support), summed per wave; cbca_list_cost_kernel
+	// declares the list unusable if a plane's sum says the pair is not the texture this path is for
+	float cost = 0;
 	auto flush = [&]() {
 		for (int i = lane; i < cnt; i += 64) {
 			const cb_u32 idx = buf[i];
@@ -268,16 +278,29 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 			bool fits = u <= 13 && dn <= 13 && rows <= 11;
 			bool small = rows <= 4;   // at most four rows of at most four values
 			cb_u32 ew[3] = {0u, 0u, 0u};
-			for (int k = 0; k < rows && fits; ++k) {
+			const int ye = rem / W, xe = rem - ye * W;
+			const bool own = A.halo && ye >= y0 && ye < y1 && (unsigned)(xe - xb - 2) < 252u;
+			float taps = 0, outside = 0;
+			for (int k = 0; k < rows && (fits || own); ++k) {
 				const int g = rem + (k - u) * W;
 				const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
 				const cb_u32 l = m & 0xffu, r = (m >> 8) & 0xffu;
-				fits = l <= 15u && r <= 15u;
-				small = small && l + r <= 3u;
-				const int j = 1 + k;
-				const cb_u32 byte = (l | (r << 4)) << ((j & 3) * 8);
-				if (j < 4) ew[0] |= byte; else if (j < 8) ew[1] |= byte; else ew[2] |= byte;
+				if (own) {
+					const int ry = ye + k - u - (y0 - 1);
+					int in = 0;
+					if ((unsigned)ry < (unsigned)(A.rb + 2)) in = max(0, min(xe + (int)r, xb + 254) - max(xe - (int)l, xb + 1) + 1);
+					taps += (float)(l + r + 1u);
+					outside += (float)((int)(l + r + 1u) - in);
+				}
+				if (fits) {
+					fits = l <= 15u && r <= 15u;
+					small = small && l + r <= 3u;
+					const int j = 1 + k;
+					const cb_u32 byte = (l | (r << 4)) << ((j & 3) * 8);
+					if (j < 4) ew[0] |= byte; else if (j < 8) ew[1] |= byte; else ew[2] |= byte;
+				}
 			}
+			cost += outside * taps;
 			if (!fits) { ew[0] = 0xffu; ew[1] = ew[2] = 0u; }
 			else ew[0] |= small ? (0xe0u | (cb_u32)u | ((cb_u32)dn << 2)) : (cb_u32)(u | (dn << 4));
 			if (written + (cb_u32)i < total) *(cb_u4 *)(slots + (size_t)(first - 1 + written + i) * 4) = cb_u4{idx, ew[0], ew[1], ew[2]};
@@ -286,15 +309,17 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 		cnt = 0;
 	};
 	cb_u32 ma[4], mb[4], mc_[4], md[4];   // rows y - 1, y, y + 1 and, on its way, y + 2
-	fetch(y0 - 1, ma);
-	fetch(y0, mb);
-	fetch(y0 + 1, mc_);
-	for (int y = y0; y < y1; ++y) {
-		fetch(y + 2 <= y1 ? y + 2 : -1, md);
+	const int ya = y0 - A.halo, yb = y1 + A.halo;   // rows the list covers (those inside the image)
+	fetch(ya - 1, ma);
+	fetch(ya, mb);
+	fetch(ya + 1, mc_);
+	for (int y = ya; y < yb; ++y) {
+		fetch(y + 2 <= yb ? y + 2 : -1, md);
+		const bool rowin = (unsigned)y < (unsigned)H;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const bool minimal = mb[j] == 0x01010101u && (ma[j] & 0xffffu) == 0x0101u && (mc_[j] & 0xffffu) == 0x0101u;
-			const bool listed = ((want >> j) & 1u) && !minimal;
+			const bool listed = rowin && ((want >> j) & 1u) && !minimal;
 			const unsigned long long bal = __ballot(listed);
 			if (PASS == 1) {
 				const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((cb_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)bal, 0));
@@ -307,10 +332,39 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 		for (int j = 0; j < 4; ++j) { ma[j] = mb[j]; mb[j] = mc_[j]; mc_[j] = md[j]; }
 	}
 	if (PASS == 0) {
-		if (lane == 0) A.hdr[A.wtab_words + 2 * w + 1] = (cb_u32)cnt;
-	} else if (cnt) {
-		flush();
+		if (lane == 0) {
+			A.hdr[A.wtab_words + 2 * w + 1] = (cb_u32)cnt;
+			if (A.halo) A.hdr[A.cost_words + w] = 0u;
+		}
+	} else {
+		if (cnt) flush();
+		if (A.halo) {
+#pragma unroll
+			for (int o = 32; o >= 1; o >>= 1) cost += __shfl_xor(cost, o);
+			if (lane == 0) A.hdr[A.cost_words + w] = __float_as_uint(cost);
+		}
 	}
+}
+
+// two-pass geometry, after PASS 1: one block per plane adds the plane's waves' cost words; more than MC_LEAN2X_COST values recomputed per
+// voxel on average means the pair has regions of large supports next to its texture -- the list is declared unusable (the overflow word)
+// and the passes go one per launch
+#ifndef MC_LEAN2X_COST
+#define MC_LEAN2X_COST 2.0f
+#endif
+__global__ void __launch_bounds__(256) cbca_list_cost_kernel(const LeanArgs A, int npl)
+{
+	__shared__ float wsum[4];
+	if (!cbca_gate(A.flags, A.route)) return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t *__restrict__ tab = A.hdr + A.cost_words + (size_t)blockIdx.x * npl;
+	float t = 0;
+	for (int i = tid; i < npl; i += 256) t += __uint_as_float(tab[i]);
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+	if (lane == 0) wsum[wv] = t;
+	__syncthreads();
+	if (tid == 0 && !(wsum[0] + wsum[1] + wsum[2] + wsum[3] <= A.cost_limit * (float)A.H * (float)A.W)) A.hdr[LH_OVERFLOW] = 1u;
 }
 
 // counts of a plane's waves -> slot numbers: wave table word 0 = slot + 1 of the wave's first entry (0: none).  One block per plane,
@@ -492,6 +546,215 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
 }
 
 
+// ---- two passes in one launch ---------------------------------------------------------------------------------------------------
+// mc_predict aggregates a volume 2 + 16 times in a row (main.lua:998-1001, 1033-1039), and on a texture each pass is a 3 x 3 stencil
+// that moves the whole volume through HBM.  This kernel runs TWO consecutive passes per launch: a wave reads R + 4 rows of 256 columns
+// of the plane, computes the R + 2 rows of the FIRST pass it needs (kept on chip: an LDS tile of its own, no barrier -- the LDS serves a
+// wave's instructions in order), then its R x 252 outputs of the SECOND pass -- the plane is read 1.5 x and written once per two passes
+// instead of read 2.5 x and written twice.  Both passes do, per output, exactly what cbca_lean_kernel does (nine additions in the
+// reference's order, adcensus.cu:356-373, the division by 9, copy-through without a partner).
+//
+// The listed outputs (supports that are not the minimal 3 x 3; cbca_classify_kernel with this kernel's geometry: the wave's R + 2
+// first-pass rows, columns 1 .. 254 of its 256) are redone by one lane per entry with the reference's loop:
+//   first pass   out of the input plane (list_entry_value, as in cbca_lean_kernel), the value replaces the tile's;
+//   second pass  (entries among the wave's own R x 252 outputs) over the first pass's values: out of the tile where the support lies
+//                inside it, and for the values outside (supports that reach over the tile's edge: arms >= 2 next to it) the first
+//                pass's value is recomputed from the input plane on the spot (first_pass_value) -- the same additions in the same order.
+// Columns: a wave's 256 columns start at 252 strip - 2; lanes 0 and 63 hold two outer columns each whose values are incomplete
+// (no neighbour) and store only their two inner ones.
+__device__ __forceinline__ float first_pass_value(const LeanArgs &A, const __amdgpu_buffer_rsrc_t &rv, int sh, int yy, int xx)
+{
+	const int W = A.W;
+	const int g = yy * W + xx;
+	if (xx + sh < 0 || xx + sh >= W) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, (cb_u32)g * 4u, 0, 0));   // adcensus.cu:353-354
+	const uint32_t mm = bytemin4(A.p0[g], A.p1[g + sh]);
+	const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
+	float sum = 0;
+	int cnt = 0;
+	for (int q = -u; q <= dn; ++q) {
+		const int gq = g + q * W;
+		const uint32_t m = bytemin4(A.p0[gq], A.p1[gq + sh]);
+		const int l = (int)(m & 0xffu), nk = l + (int)((m >> 8) & 0xffu) + 1;
+		for (int k = 0; k < nk; ++k) sum += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, (cb_u32)(gq - l + k) * 4u, 0, 0));
+		cnt += nk;
+	}
+	return sum / (float)cnt;
+}
+
+// second-pass value of the listed output (y, x) (entry e, rem = y * W + x): the reference's loop over the first pass's values
+template <int R>
+__device__ __forceinline__ float second_pass_entry(const LeanArgs &A, const __amdgpu_buffer_rsrc_t &rv, const float *__restrict__ T, int d, const cb_u4 &e,
+                                                   cb_u32 rem, int y, int x, int y0, int xb)
+{
+	const int W = A.W;
+	const int sh = d * A.direction;
+	const cb_u32 b0 = e.y & 0xffu;
+	const bool lookup = b0 == 0xffu, small = (b0 & 0xf0u) == 0xe0u;
+	int u, rows;
+	if (lookup) {
+		const uint32_t mm = bytemin4(A.p0[rem], A.p1[(int)rem + sh]);
+		u = (int)((mm >> 16) & 0xffu);
+		rows = u + (int)(mm >> 24) + 1;
+	} else if (small) {
+		u = (int)(b0 & 3u);
+		rows = u + (int)((b0 >> 2) & 3u) + 1;
+	} else {
+		u = (int)(b0 & 15u);
+		rows = u + (int)(b0 >> 4) + 1;
+	}
+	float sum = 0;
+	int cnt = 0;
+	for (int k = 0; k < rows; ++k) {
+		const int yy = y + k - u;
+		int l, nk;
+		if (lookup) {
+			const int g = (int)rem + (k - u) * W;
+			const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
+			l = (int)(m & 0xffu);
+			nk = l + (int)((m >> 8) & 0xffu) + 1;
+		} else {
+			const cb_u32 lr = entry_byte(e, 1 + k);
+			l = (int)(lr & 15u);
+			nk = l + (int)(lr >> 4) + 1;
+		}
+		const int ry = yy - (y0 - 1);
+		const bool row_in = (unsigned)ry < (unsigned)(R + 2);
+		for (int c = 0; c < nk; ++c) {
+			const int xx = x - l + c;
+			const int cx = xx - xb;
+			float t;
+			if (row_in && (unsigned)(cx - 1) < 254u) t = T[ry * 256 + cx];
+			else t = first_pass_value(A, rv, sh, yy, xx);
+			sum += t;
+		}
+		cnt += nk;
+	}
+	return sum / (float)cnt;
+}
+
+// one row of a pass: the minimal 3 x 3 mean of the lane's four columns out of rows a, b, c (and the neighbouring lanes' columns), copy-through
+// where the output has no partner
+__device__ __forceinline__ cb_f4 lean_row(const cb_f4 &a, const cb_f4 &b, const cb_f4 &c, cb_u32 inr)
+{
+	const float ra[6] = {lane_from_below(a.w, 0.0f), a.x, a.y, a.z, a.w, lane_from_above(a.x, 0.0f)};
+	const float rb[6] = {lane_from_below(b.w, 0.0f), b.x, b.y, b.z, b.w, lane_from_above(b.x, 0.0f)};
+	const float rc[6] = {lane_from_below(c.w, 0.0f), c.x, c.y, c.z, c.w, lane_from_above(c.x, 0.0f)};
+	float sum[4], res[4];
+	bool fast = true;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		float t = 0;
+		t += ra[j]; t += ra[j + 1]; t += ra[j + 2];
+		t += rb[j]; t += rb[j + 1]; t += rb[j + 2];
+		t += rc[j]; t += rc[j + 1]; t += rc[j + 2];
+		sum[j] = t;
+		fast = fast && div9_ok(t);
+		res[j] = div9(t);
+	}
+	if (__any(!fast)) {   // (zeros, denormals, huge values, infinities, NaNs somewhere in the wave's row)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) res[j] = sum[j] / 9.0f;
+	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j) res[j] = ((inr >> j) & 1u) ? res[j] : rb[j + 1];
+	return cb_f4{res[0], res[1], res[2], res[3]};
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
+{
+	__shared__ __attribute__((aligned(16))) float tiles[4][(R + 2) * 256];
+	if (!lean_runs(A)) return;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	long long w;
+	int d, y0, y1, xb;
+	if (!lean_wave(A, wv, w, d, y0, y1, xb)) return;
+	float *__restrict__ T = tiles[wv];
+	const int H = A.H, W = A.W;
+	const int HWi = H * W;
+	const int sh = d * A.direction;
+	const int xs = xb + 4 * lane;
+	const cb_u32 OOB = 0x80000000u;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
+	cb_u32 inr = 0;   // bit j: the output has a partner (adcensus.cu:353)
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+		if (xs + j + sh >= 0 && xs + j + sh < W) inr |= 1u << j;
+	// input rows y0 - 2 .. y0 + R + 1, all requested before the first is used; rows outside the image: zeros.  The first strip's lane 0
+	// starts two pixels before its row: the previous row's last two -- never an operand of an output that is not listed -- except in
+	// row 0, where that offset lies before the plane: its two real columns come from a load of their own (fx).
+	cb_u4 v[R + 4];
+#pragma unroll
+	for (int k = 0; k < R + 4; ++k) {
+		const int r = y0 - 2 + k;
+		const bool ok = (unsigned)r < (unsigned)H && xs < W && r * W + xs >= 0;
+		v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (cb_u32)(r * W + xs) * 4u : OOB, 0, 0);
+	}
+	const bool row0_edge = y0 == 0 && xs < 0;   // (xs = -2: columns 0 and 1 of row 0 = words 0 and 1 of the plane)
+	const cb_u2 fx = __builtin_amdgcn_raw_buffer_load_b64(rv, row0_edge ? 0u : OOB, 0, 0);
+	// the wave's entries: its words of the wave table
+	const uint32_t *__restrict__ slots = A.hdr + A.slots_words;
+	const cb_u32 seg = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w]);   // slot + 1 of the wave's first entry
+	cb_u32 nent = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w + 1]);
+	if (seg == 0 || seg > A.cap) nent = 0;
+	else nent = min(nent, A.cap - (seg - 1));
+	if (row0_edge) { v[2].z = fx.x; v[2].w = fx.y; }
+
+	// first pass: rows y0 - 1 .. y0 + R into the tile
+#pragma unroll
+	for (int k = 0; k < R + 2; ++k) {
+		const cb_f4 a = __builtin_bit_cast(cb_f4, v[k]), b = __builtin_bit_cast(cb_f4, v[k + 1]), c = __builtin_bit_cast(cb_f4, v[k + 2]);
+		*(cb_f4 *)(T + k * 256 + 4 * lane) = lean_row(a, b, c, inr);
+		__builtin_amdgcn_sched_barrier(0);   // (a row at a time: otherwise every row's sums are hoisted and the registers of all of them are live at once)
+	}
+	// ... its listed outputs, out of the input plane
+	for (cb_u32 i = (cb_u32)lane; i < nent; i += 64) {
+		const cb_u4 e = *(const cb_u4 *)(slots + (size_t)(seg - 1 + i) * 4);
+		const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;   // y * W + x
+		if (rem >= (cb_u32)HWi) continue;   // (not this plane's: never written by cbca_classify_kernel)
+		const int y = (int)(rem / (cb_u32)W), x = (int)rem - y * W;
+		const int ry = y - (y0 - 1), cx = x - xb;
+		if ((unsigned)ry >= (unsigned)(R + 2) || (unsigned)cx >= 256u) continue;
+		T[ry * 256 + cx] = list_entry_value(A, rv, d, e, rem);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+	// second pass: the wave's R rows out of the tile
+	cb_f4 m[R + 2];
+#pragma unroll
+	for (int k = 0; k < R + 2; ++k) m[k] = *(const cb_f4 *)(T + k * 256 + 4 * lane);
+	const bool edge = lane == 0 || lane == 63;
+	const int xe = lane == 0 ? xs + 2 : xs;   // first of an edge lane's two stored columns
+#pragma unroll
+	for (int k = 0; k < R; ++k) {
+		const int yo = y0 + k;
+		const cb_f4 res = lean_row(m[k], m[k + 1], m[k + 2], inr);
+		const bool myrow = yo < y1;
+		const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, myrow ? (yo + 1) * W * 4 : 0, 0x00020000);
+		__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res.x), __float_as_uint(res.y), __float_as_uint(res.z), __float_as_uint(res.w)},
+		                                       rrow, (myrow && !edge && xs < W) ? (cb_u32)(yo * W + xs) * 4u : OOB, 0, 0);
+		const cb_u2 two = lane == 0 ? cb_u2{__float_as_uint(res.z), __float_as_uint(res.w)} : cb_u2{__float_as_uint(res.x), __float_as_uint(res.y)};
+		__builtin_amdgcn_raw_buffer_store_b64(two, rrow, (myrow && edge && xe >= 0 && xe < W) ? (cb_u32)(yo * W + xe) * 4u : OOB, 0, 0);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	// ... its listed outputs: over the first pass's values; their stores after the wave's own stores have completed (the same addresses,
+	// written by other lanes)
+	if (nent) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		for (cb_u32 i = (cb_u32)lane; i < nent; i += 64) {
+			const cb_u4 e = *(const cb_u4 *)(slots + (size_t)(seg - 1 + i) * 4);
+			const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;
+			if (rem >= (cb_u32)HWi) continue;
+			const int y = (int)(rem / (cb_u32)W), x = (int)rem - y * W;
+			if (y < y0 || y >= y1 || (unsigned)(x - xb - 2) >= 252u) continue;   // (the wave's own outputs only)
+			A.vout[(size_t)d * HWi + rem] = second_pass_entry<R>(A, rv, T, d, e, rem, y, x, y0, xb);
+		}
+	}
+}
+
 // rows per wave / launch variant mc_predict uses (cfg.lean_rb = 0 / cfg.lean_variant < 0): measured at 1000 x 1500 x 256, one box
 // (profiles/r04_cbca_lean.txt): 8 rows 0.602 / 0.620 ms (address order / a band per XCD), 4 rows 0.601 / 0.601, 2 rows 0.652 / 0.635;
 // the classification costs 0.54 / 0.88 / 1.3 ms per direction
@@ -502,9 +765,14 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
 #define MC_LEAN_VARIANT_DEFAULT 0
 #endif
 static int lean_rows(int rb) { return (rb == 2 || rb == 4 || rb == 8) ? rb : MC_LEAN_RB_DEFAULT; }
+// ... of the two-pass kernel (cfg.lean_rb; measured at 1000 x 1500 x 256: DESIGN section 7)
+#ifndef MC_LEAN2X_RB_DEFAULT
+#define MC_LEAN2X_RB_DEFAULT 8
+#endif
+static int lean2x_rows(int rb) { return (rb == 4 || rb == 8 || rb == 12) ? rb : MC_LEAN2X_RB_DEFAULT; }
 
 static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
-                          int route, int rb, int cap_limit = 0, int order = 0)
+                          int route, int rb, int cap_limit = 0, int order = 0, bool two_pass = false)
 {
 	LeanArgs A;
 	const CbcaScratch cs = cbca_scratch(packed, H, W);
@@ -512,16 +780,20 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	A.vin = vin; A.vout = vout;
 	A.hdr = (uint32_t *)plan;
 	A.D = D; A.H = H; A.W = W; A.direction = direction;
-	A.gx = (int)cdiv(W, 256);
-	A.rb = lean_rows(rb);
+	A.pitch = two_pass ? 252 : 256; A.xoff = two_pass ? -2 : 0; A.halo = two_pass ? 1 : 0;
+	A.gx = (int)cdiv(W, A.pitch);
+	A.rb = two_pass ? lean2x_rows(rb) : lean_rows(rb);
+	A.rbcode = (cb_u32)A.rb | (two_pass ? 0x100u : 0u);
 	A.gy = (int)cdiv(H, A.rb);
 	A.order = order;
 	A.gyb = (int)cdiv(A.gy, 8);
 	A.gx_rcp = (cb_u32)((((uint64_t)1 << 32) + A.gx - 1) / A.gx);
 	const int64_t waves = (int64_t)A.gx * A.gy * D;
-	// [header LH_WORDS | wave table: 2 words per wave, canonical order (plane, chunk, strip) | slots: 16 bytes each, capd per plane]
+	// [header LH_WORDS | wave table: 2 words per wave, canonical order (plane, chunk, strip) | two-pass geometry: a cost word per wave |
+	//  slots: 16 bytes each, capd per plane]
 	A.wtab_words = LH_WORDS;
-	A.slots_words = (uint32_t)((A.wtab_words + 2 * waves + 3) / 4 * 4);
+	A.cost_words = (uint32_t)(A.wtab_words + 2 * waves);
+	A.slots_words = (uint32_t)((A.cost_words + (two_pass ? waves : 0) + 3) / 4 * 4);
 	const int64_t room = (int64_t)plan_bytes / 4 - A.slots_words;
 	int64_t cap = std::max<int64_t>(0, std::min<int64_t>(room / 4, 0x3ffffff0));
 	if (cap_limit > 0) cap = std::min<int64_t>(cap, cap_limit);   // (test hook: a list that does not fit)
@@ -529,14 +801,15 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	A.cap = A.capd * (uint32_t)D;
 	A.flags = cs.flag;
 	A.route = route;
+	A.cost_limit = MC_LEAN2X_COST;
 	return A;
 }
 
 // rows per wave of the lean / classify kernels for a problem (rb > 0: forced): the list is valid for this value only
-int cbca_lean_rows(int D, int H, int W, int rb)
+int cbca_lean_rows(int D, int H, int W, int rb, bool two_pass)
 {
 	(void)D; (void)H; (void)W;
-	return lean_rows(rb);
+	return two_pass ? (lean2x_rows(rb) | 0x100) : lean_rows(rb);   // (the value of the list header's LH_RB word)
 }
 
 // blocks of 4 waves: x over one plane's (chunk, strip) pairs -- order 1: eight bands of gyb chunks, band = blockIdx.x & 7 --, y = plane
@@ -546,18 +819,19 @@ static dim3 lean_grid(const LeanArgs &A)
 	return dim3(per_plane, (unsigned)A.D);
 }
 
-bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes)
+bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes, bool two_pass)
 {
 	if ((int64_t)D * H * W >= ((int64_t)1 << 32) || D > 65535) return false;   // (32-bit voxel indices in the entries; the plane is blockIdx.y)
-	const LeanArgs A = lean_args(nullptr, nullptr, plan_bytes, nullptr, nullptr, D, H, W, -1, 0, 0);
+	const LeanArgs A = lean_args(nullptr, nullptr, plan_bytes, nullptr, nullptr, D, H, W, -1, 0, 0, 0, 0, two_pass);
 	return A.capd >= 2 && (int64_t)A.gx * A.gy < 65536 && (int64_t)A.gx * A.gy * D < ((int64_t)1 << 30);
 }
 
 // once per pair and direction (before the first pass): the list of outputs whose support is not the minimal 3 x 3
 int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, int rb, int cap_limit,
-                  hipStream_t st)
+                  hipStream_t st, bool two_pass, float cost_limit)
 {
-	const LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb, cap_limit);
+	LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb, cap_limit, 0, two_pass);
+	A.cost_limit = cost_limit > 0 ? cost_limit : MC_LEAN2X_COST;
 	const hipError_t e = hipMemsetAsync(plan, 0, LH_WORDS * 4, st);   // (the header: magic and overflow word; the wave table is written in full)
 	if (e != hipSuccess) {
 		set_error("cbca_classify: %s", hipGetErrorString(e));
@@ -566,6 +840,7 @@ int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int 
 	hipLaunchKernelGGL(cbca_classify_kernel<0>, lean_grid(A), dim3(256), 0, st, A);
 	hipLaunchKernelGGL(cbca_list_scan_kernel, dim3((unsigned)D), dim3(256), 0, st, A, A.gx * A.gy);
 	hipLaunchKernelGGL(cbca_classify_kernel<1>, lean_grid(A), dim3(256), 0, st, A);
+	if (two_pass) hipLaunchKernelGGL(cbca_list_cost_kernel, dim3((unsigned)D), dim3(256), 0, st, A, A.gx * A.gy);
 	return check_launch("cbca_classify");
 }
 
@@ -598,6 +873,19 @@ int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const flo
 	if (rc || !own_launch) return rc;
 	hipLaunchKernelGGL(cbca_list_kernel, blocks, dim3(256), 0, st, A);
 	return check_launch("cbca_list");
+}
+
+// two aggregation passes in one launch (cbca_lean2x_kernel) out of the list cbca_classify(..., two_pass = true) wrote: vout = the volume
+// after the second pass.  Stands down (and writes nothing) unless the pair's route is `route` and the list is this problem's.
+int cbca_lean2x(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
+                int route, hipStream_t st, const CbcaCfg &cfg)
+{
+	const LeanArgs A = lean_args(packed, (void *)plan, plan_bytes, vin, vout, D, H, W, direction, route, cfg.lean_rb, cfg.nd, 0, true);
+	const dim3 blocks = lean_grid(A);
+	if (A.rb == 4) hipLaunchKernelGGL(cbca_lean2x_kernel<4>, blocks, dim3(256), 0, st, A);
+	else if (A.rb == 12) hipLaunchKernelGGL(cbca_lean2x_kernel<12>, blocks, dim3(256), 0, st, A);
+	else hipLaunchKernelGGL(cbca_lean2x_kernel<8>, blocks, dim3(256), 0, st, A);
+	return check_launch("cbca_lean2x");
 }
 
 }  // namespace mc

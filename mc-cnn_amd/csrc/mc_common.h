@@ -37,6 +37,8 @@ struct CbcaCfg {
 	int lean_rb = 0;   // ... rows per wave of the lean kernels that wrote / read the list (0 = the product's choice)
 	int lean_variant = -1;  // ... launch variant of the lean kernels (-1 = the product's choice; cbca_lean.hip)
 	bool lean = false; // route CR_STRIP is served by the lean + list kernels (cbca_lean.hip) out of the list cbca_classify wrote to *plan
+	bool lean_two_pass = false;   // ... by cbca_lean2x (two passes per launch, launched by the caller), whose list has another wave geometry: cbca_by_arms
+	                              // then launches only the kernels of the other routes and the strip kernel as that list's fallback
 };
 
 // ---- wave64 cross-lane primitives (DPP, no LDS round trip) -------------------
