@@ -632,31 +632,48 @@ __device__ __forceinline__ float second_pass_entry(const LeanArgs &A, const __am
 	return sum / (float)cnt;
 }
 
-// one row of a pass: the minimal 3 x 3 mean of the lane's four columns out of rows a, b, c (and the neighbouring lanes' columns), copy-through
-// where the output has no partner
-__device__ __forceinline__ cb_f4 lean_row(const cb_f4 &a, const cb_f4 &b, const cb_f4 &c, cb_u32 inr)
+// a row of the lane's four columns with the neighbouring lanes' columns beside them (columns xs - 1 .. xs + 4): two DPP moves per row,
+// shared by the three output rows the row is an operand of
+struct Row6 { float c[6]; };
+__device__ __forceinline__ Row6 with_neighbours(const cb_f4 &v)
 {
-	const float ra[6] = {lane_from_below(a.w, 0.0f), a.x, a.y, a.z, a.w, lane_from_above(a.x, 0.0f)};
-	const float rb[6] = {lane_from_below(b.w, 0.0f), b.x, b.y, b.z, b.w, lane_from_above(b.x, 0.0f)};
-	const float rc[6] = {lane_from_below(c.w, 0.0f), c.x, c.y, c.z, c.w, lane_from_above(c.x, 0.0f)};
+	Row6 r;
+	r.c[0] = lane_from_below(v.w, 0.0f); r.c[1] = v.x; r.c[2] = v.y; r.c[3] = v.z; r.c[4] = v.w; r.c[5] = lane_from_above(v.x, 0.0f);
+	return r;
+}
+
+// one row of a pass: the minimal 3 x 3 mean of the lane's four columns out of rows a, b, c, copy-through where the output has no partner
+// (allin: every output of the wave has one -- wave-uniform).  The reference's sum starts at +0.0 (adcensus.cu:356); 0 + x is x except
+// for x = -0.0, and the sum of the nine then differs only if it is a zero -- which div9_ok sends to the exact path below, together with
+// everything else the three-operation division does not cover: there the chain is redone from +0.0.  So the common path adds eight times.
+__device__ __forceinline__ cb_f4 lean_row(const Row6 &a, const Row6 &b, const Row6 &c, cb_u32 inr, bool allin)
+{
 	float sum[4], res[4];
 	bool fast = true;
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
-		float t = 0;
-		t += ra[j]; t += ra[j + 1]; t += ra[j + 2];
-		t += rb[j]; t += rb[j + 1]; t += rb[j + 2];
-		t += rc[j]; t += rc[j + 1]; t += rc[j + 2];
+		float t = a.c[j] + a.c[j + 1];
+		t += a.c[j + 2];
+		t += b.c[j]; t += b.c[j + 1]; t += b.c[j + 2];
+		t += c.c[j]; t += c.c[j + 1]; t += c.c[j + 2];
 		sum[j] = t;
 		fast = fast && div9_ok(t);
 		res[j] = div9(t);
 	}
 	if (__any(!fast)) {   // (zeros, denormals, huge values, infinities, NaNs somewhere in the wave's row)
 #pragma unroll
-		for (int j = 0; j < 4; ++j) res[j] = sum[j] / 9.0f;
+		for (int j = 0; j < 4; ++j) {
+			float t = 0;
+			t += a.c[j]; t += a.c[j + 1]; t += a.c[j + 2];
+			t += b.c[j]; t += b.c[j + 1]; t += b.c[j + 2];
+			t += c.c[j]; t += c.c[j + 1]; t += c.c[j + 2];
+			res[j] = t / 9.0f;
+		}
 	}
+	if (!allin) {
 #pragma unroll
-	for (int j = 0; j < 4; ++j) res[j] = ((inr >> j) & 1u) ? res[j] : rb[j + 1];
+		for (int j = 0; j < 4; ++j) res[j] = ((inr >> j) & 1u) ? res[j] : b.c[j + 1];
+	}
 	return cb_f4{res[0], res[1], res[2], res[3]};
 }
 
@@ -691,22 +708,30 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 		const bool ok = (unsigned)r < (unsigned)H && xs < W && r * W + xs >= 0;
 		v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (cb_u32)(r * W + xs) * 4u : OOB, 0, 0);
 	}
-	const bool row0_edge = y0 == 0 && xs < 0;   // (xs = -2: columns 0 and 1 of row 0 = words 0 and 1 of the plane)
-	const cb_u2 fx = __builtin_amdgcn_raw_buffer_load_b64(rv, row0_edge ? 0u : OOB, 0, 0);
+	// (xs = -2, rows 0 and -- images one pixel wide -- 1: the row's columns 0 and 1 are the plane's words r W and r W + 1)
+	const bool edge0 = y0 == 0 && xs < 0 && 0 < H, edge1 = y0 == 0 && xs < 0 && W + xs < 0 && 1 < H;
+	const cb_u2 fx0 = __builtin_amdgcn_raw_buffer_load_b64(rv, edge0 ? 0u : OOB, 0, 0);
+	const cb_u2 fx1 = __builtin_amdgcn_raw_buffer_load_b64(rv, edge1 ? (cb_u32)W * 4u : OOB, 0, 0);
 	// the wave's entries: its words of the wave table
 	const uint32_t *__restrict__ slots = A.hdr + A.slots_words;
 	const cb_u32 seg = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w]);   // slot + 1 of the wave's first entry
 	cb_u32 nent = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w + 1]);
 	if (seg == 0 || seg > A.cap) nent = 0;
 	else nent = min(nent, A.cap - (seg - 1));
-	if (row0_edge) { v[2].z = fx.x; v[2].w = fx.y; }
+	if (edge0) { v[2].z = fx0.x; v[2].w = fx0.y; }
+	if (edge1) { v[3].z = fx1.x; v[3].w = fx1.y; }
+	const bool allin = __all(inr == 15u);
 
 	// first pass: rows y0 - 1 .. y0 + R into the tile
+	{
+		Row6 a = with_neighbours(__builtin_bit_cast(cb_f4, v[0])), b = with_neighbours(__builtin_bit_cast(cb_f4, v[1]));
 #pragma unroll
-	for (int k = 0; k < R + 2; ++k) {
-		const cb_f4 a = __builtin_bit_cast(cb_f4, v[k]), b = __builtin_bit_cast(cb_f4, v[k + 1]), c = __builtin_bit_cast(cb_f4, v[k + 2]);
-		*(cb_f4 *)(T + k * 256 + 4 * lane) = lean_row(a, b, c, inr);
-		__builtin_amdgcn_sched_barrier(0);   // (a row at a time: otherwise every row's sums are hoisted and the registers of all of them are live at once)
+		for (int k = 0; k < R + 2; ++k) {
+			const Row6 c = with_neighbours(__builtin_bit_cast(cb_f4, v[k + 2]));
+			*(cb_f4 *)(T + k * 256 + 4 * lane) = lean_row(a, b, c, inr, allin);
+			a = b; b = c;
+			__builtin_amdgcn_sched_barrier(0);   // (a row at a time: otherwise every row's sums are hoisted and the registers of all of them are live at once)
+		}
 	}
 	// ... its listed outputs, out of the input plane
 	for (cb_u32 i = (cb_u32)lane; i < nent; i += 64) {
@@ -728,10 +753,13 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 	for (int k = 0; k < R + 2; ++k) m[k] = *(const cb_f4 *)(T + k * 256 + 4 * lane);
 	const bool edge = lane == 0 || lane == 63;
 	const int xe = lane == 0 ? xs + 2 : xs;   // first of an edge lane's two stored columns
+	Row6 ma = with_neighbours(m[0]), mb = with_neighbours(m[1]);
 #pragma unroll
 	for (int k = 0; k < R; ++k) {
 		const int yo = y0 + k;
-		const cb_f4 res = lean_row(m[k], m[k + 1], m[k + 2], inr);
+		const Row6 mc = with_neighbours(m[k + 2]);
+		const cb_f4 res = lean_row(ma, mb, mc, inr, allin);
+		ma = mb; mb = mc;
 		const bool myrow = yo < y1;
 		const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, myrow ? (yo + 1) * W * 4 : 0, 0x00020000);
 		__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res.x), __float_as_uint(res.y), __float_as_uint(res.z), __float_as_uint(res.w)},

@@ -48,7 +48,7 @@ def test_two_passes_in_one_launch(mc, oracle, H, W, D, mk, L1, tau1):
         assert same_bits(got, want), diff_report(got, want, "listing launch, dir=%d" % direction)
         hdr = mc.adcensus.cbca_cfg_list_header(out.device, D, H, W, 10)
         assert hdr[2:5] == [D, H, W] and hdr[5] == direction + 1 and hdr[7] == 0x108, hdr
-        if mk == "smooth" and L1 == 14 and H * W > 2000:   # a texture: the two-pass kernel itself must have run
+        if mk == "smooth" and L1 == 14 and H >= 16 and W >= 64:   # a texture: the two-pass kernel itself must have run
             assert hdr[1] == 0, "the texture's list was declared unusable: %r" % (hdr,)
         out = torch.full((1, D, H, W), -7.0, device="cuda")   # another volume of the same pair out of the same list
         mc.adcensus.cbca_cfg(dev(x0c), dev(x1c), dev(vol2), out, direction, form=11)
