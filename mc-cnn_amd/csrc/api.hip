@@ -42,7 +42,7 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 size_t cbca_plan_bytes(int D, int H, int W);
 int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, int W, int direction, int arm_class, int route,
                hipStream_t st, const CbcaCfg &cfg = CbcaCfg());
-bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes, bool two_pass = false);
+bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes, bool two_pass = false, int rb = 0);
 int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int H, int W, int direction, int route, int rb, int cap_limit,
                   hipStream_t st, bool two_pass = false, float cost_limit = 0);
 int cbca_lean2x(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
@@ -676,23 +676,25 @@ int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, floa
 		const size_t vb = (size_t)D * H * W * sizeof(float);
 		MC_REQUIRE(scratch_bytes >= off + pb + vb, "mc_cbca_ws_cfg: scratch holds %zu bytes, needs %zu with the list and a volume", scratch_bytes, off + pb + vb);
 		MC_REQUIRE((uintptr_t)scratch % 16 == 0, "mc_cbca_ws_cfg: scratch must be 16-byte aligned for the list");
-		MC_REQUIRE(cbca_lean_fits(D, H, W, pb, true), "mc_cbca_ws_cfg: volume too large for 32-bit list entries");
 		cfg.plan = (char *)scratch + off;
 		cfg.plan_bytes = pb;
 		cfg.lean_rb = rb;
 		cfg.lean_two_pass = true;
-		cfg.d0 = 0; cfg.nd = nd;
+		cfg.d0 = 0; cfg.nd = 0;
 		float *mid = (float *)((char *)scratch + off + pb);
-		if (form == 10) {
-			rc = cbca_classify(scratch, cfg.plan, cfg.plan_bytes, D, H, W, direction, CR_NOT_DIRECT, rb, nd, st, true, (float)d0);   // (d0 > 0: the cost limit, in values per voxel)
+		const bool fits = cbca_lean_fits(D, H, W, pb, true, rb);   // (the records of this many rows per wave fit the area; else: the strip kernel, unconditionally)
+		if (fits && form == 10) {
+			rc = cbca_classify(scratch, cfg.plan, cfg.plan_bytes, D, H, W, direction, CR_NOT_DIRECT, rb, 0, st, true, (float)d0);   // (d0 > 0: the cost limit, in values per voxel)
 			if (rc) return rc;
 		}
-		rc = cbca_lean2x(scratch, cfg.plan, cfg.plan_bytes, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT, st, cfg);
+		if (fits) {
+			rc = cbca_lean2x(scratch, cfg.plan, cfg.plan_bytes, vol_in, vol_out, D, H, W, direction, CR_NOT_DIRECT, st, cfg);
+			if (rc) return rc;
+		}
+		const int sroute = fits ? CR_NOT_DIRECT_IF_NO_LIST : CR_NOT_DIRECT;
+		rc = cbca_strips(scratch, vol_in, mid, D, H, W, direction, sroute, st, cfg);
 		if (rc) return rc;
-		cfg.nd = 0;
-		rc = cbca_strips(scratch, vol_in, mid, D, H, W, direction, CR_NOT_DIRECT_IF_NO_LIST, st, cfg);
-		if (rc) return rc;
-		rc = cbca_strips(scratch, mid, vol_out, D, H, W, direction, CR_NOT_DIRECT_IF_NO_LIST, st, cfg);
+		rc = cbca_strips(scratch, mid, vol_out, D, H, W, direction, sroute, st, cfg);
 		if (rc) return rc;
 		rc = cbca_if_overflow(x0c, x1c, scratch, vol_in, mid, D, H, W, direction, st);
 		if (rc) return rc;

@@ -29,15 +29,13 @@ struct LeanArgs {
 	uint32_t capd;               // slots per plane (the slots are allotted per plane)
 	uint32_t wtab_words;         // word offset of the wave table: per wave of the lean kernel {slot + 1 of its first entry, its entries}
 	float cost_limit;            // two-pass geometry: values recomputed per voxel, on average over a plane, beyond which the list is declared unusable
-	uint32_t cost_words;         // two-pass geometry: word offset of one float per wave -- what its second-pass entries cost beyond their own supports
 	uint32_t slots_words;        // word offset of the slots (16 bytes each)
 	uint32_t cap;                // slots the list can hold
 	int D, H, W, direction;
 	int rb, gx, gy;              // rows per wave, strips per row, row chunks
 	cb_u32 gx_rcp;               // ceil(2^32 / gx)
 	int order, gyb;              // wave order: 0 linear over the volume, 1 one band of gyb row chunks per XCD (blockIdx & 7), each swept linearly
-	int pitch, xoff, halo;       // a wave's 256 columns start at strip * pitch + xoff; the list covers halo rows above / below the wave's rows and its
-	                             // columns [halo, 256 - halo) (single pass: 256, 0, 0; two passes in one launch, cbca_lean2x_kernel: 252, -2, 1)
+	int pitch, xoff;             // a wave's 256 columns start at strip * pitch + xoff (single pass: 256, 0; two passes in one launch: 252, -2)
 	cb_u32 rbcode;               // header word LH_RB of a list of this geometry: rb, + 0x100 for the two-pass geometry
 	const uint32_t *flags;       // cbca_pack's flag words
 	int route;
@@ -248,10 +246,10 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
 	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
-	cb_u32 want = 0;   // bit j: output column exists, has a partner (adcensus.cu:353) and is one this wave's list covers
+	cb_u32 want = 0;   // bit j: output column exists and has a partner (adcensus.cu:353)
 #pragma unroll
 	for (int j = 0; j < 4; ++j)
-		if (xs + j >= 0 && xs + j < W && xs + j + sh >= 0 && xs + j + sh < W && (unsigned)(4 * lane + j - A.halo) < (unsigned)(256 - 2 * A.halo)) want |= 1u << j;
+		if (xs + j < W && xs + j + sh >= 0 && xs + j + sh < W) want |= 1u << j;
 	// combined lengths of row r for this lane's four columns (rows outside the image: 0 = "not the unit arm")
 	auto fetch = [&](int r, cb_u32 (&m)[4]) {
 		const bool rok = r >= 0 && r < H;
@@ -263,11 +261,6 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 	};
 	int cnt = 0;         // PASS 0: the count; PASS 1: entries waiting in LDS
 	cb_u32 written = 0;  // PASS 1: entries already in their slots
-	// two-pass geometry: a second-pass entry (one among the wave's own outputs) sums FIRST-pass values; those outside the wave's tile
-	// (rows y0 - 1 .. y0 + rb, columns 1 .. 254) are recomputed from the input by cbca_lean2x_kernel, each at the price of its own
-	// support -- estimated here as (values outside the tile) x (values of the entry's support), summed per wave; cbca_list_cost_kernel
-	// declares the list unusable if a plane's sum says the pair is not the texture this path is for
-	float cost = 0;
 	auto flush = [&]() {
 		for (int i = lane; i < cnt; i += 64) {
 			const cb_u32 idx = buf[i];
@@ -278,29 +271,16 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 			bool fits = u <= 13 && dn <= 13 && rows <= 11;
 			bool small = rows <= 4;   // at most four rows of at most four values
 			cb_u32 ew[3] = {0u, 0u, 0u};
-			const int ye = rem / W, xe = rem - ye * W;
-			const bool own = A.halo && ye >= y0 && ye < y1 && (unsigned)(xe - xb - 2) < 252u;
-			float taps = 0, outside = 0;
-			for (int k = 0; k < rows && (fits || own); ++k) {
+			for (int k = 0; k < rows && fits; ++k) {
 				const int g = rem + (k - u) * W;
 				const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
 				const cb_u32 l = m & 0xffu, r = (m >> 8) & 0xffu;
-				if (own) {
-					const int ry = ye + k - u - (y0 - 1);
-					int in = 0;
-					if ((unsigned)ry < (unsigned)(A.rb + 2)) in = max(0, min(xe + (int)r, xb + 254) - max(xe - (int)l, xb + 1) + 1);
-					taps += (float)(l + r + 1u);
-					outside += (float)((int)(l + r + 1u) - in);
-				}
-				if (fits) {
-					fits = l <= 15u && r <= 15u;
-					small = small && l + r <= 3u;
-					const int j = 1 + k;
-					const cb_u32 byte = (l | (r << 4)) << ((j & 3) * 8);
-					if (j < 4) ew[0] |= byte; else if (j < 8) ew[1] |= byte; else ew[2] |= byte;
-				}
+				fits = l <= 15u && r <= 15u;
+				small = small && l + r <= 3u;
+				const int j = 1 + k;
+				const cb_u32 byte = (l | (r << 4)) << ((j & 3) * 8);
+				if (j < 4) ew[0] |= byte; else if (j < 8) ew[1] |= byte; else ew[2] |= byte;
 			}
-			cost += outside * taps;
 			if (!fits) { ew[0] = 0xffu; ew[1] = ew[2] = 0u; }
 			else ew[0] |= small ? (0xe0u | (cb_u32)u | ((cb_u32)dn << 2)) : (cb_u32)(u | (dn << 4));
 			if (written + (cb_u32)i < total) *(cb_u4 *)(slots + (size_t)(first - 1 + written + i) * 4) = cb_u4{idx, ew[0], ew[1], ew[2]};
@@ -309,17 +289,15 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 		cnt = 0;
 	};
 	cb_u32 ma[4], mb[4], mc_[4], md[4];   // rows y - 1, y, y + 1 and, on its way, y + 2
-	const int ya = y0 - A.halo, yb = y1 + A.halo;   // rows the list covers (those inside the image)
-	fetch(ya - 1, ma);
-	fetch(ya, mb);
-	fetch(ya + 1, mc_);
-	for (int y = ya; y < yb; ++y) {
-		fetch(y + 2 <= yb ? y + 2 : -1, md);
-		const bool rowin = (unsigned)y < (unsigned)H;
+	fetch(y0 - 1, ma);
+	fetch(y0, mb);
+	fetch(y0 + 1, mc_);
+	for (int y = y0; y < y1; ++y) {
+		fetch(y + 2 <= y1 ? y + 2 : -1, md);
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const bool minimal = mb[j] == 0x01010101u && (ma[j] & 0xffffu) == 0x0101u && (mc_[j] & 0xffffu) == 0x0101u;
-			const bool listed = rowin && ((want >> j) & 1u) && !minimal;
+			const bool listed = ((want >> j) & 1u) && !minimal;
 			const unsigned long long bal = __ballot(listed);
 			if (PASS == 1) {
 				const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((cb_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)bal, 0));
@@ -332,39 +310,10 @@ __global__ void __launch_bounds__(256) cbca_classify_kernel(const LeanArgs A)
 		for (int j = 0; j < 4; ++j) { ma[j] = mb[j]; mb[j] = mc_[j]; mc_[j] = md[j]; }
 	}
 	if (PASS == 0) {
-		if (lane == 0) {
-			A.hdr[A.wtab_words + 2 * w + 1] = (cb_u32)cnt;
-			if (A.halo) A.hdr[A.cost_words + w] = 0u;
-		}
-	} else {
-		if (cnt) flush();
-		if (A.halo) {
-#pragma unroll
-			for (int o = 32; o >= 1; o >>= 1) cost += __shfl_xor(cost, o);
-			if (lane == 0) A.hdr[A.cost_words + w] = __float_as_uint(cost);
-		}
+		if (lane == 0) A.hdr[A.wtab_words + 2 * w + 1] = (cb_u32)cnt;
+	} else if (cnt) {
+		flush();
 	}
-}
-
-// two-pass geometry, after PASS 1: one block per plane adds the plane's waves' cost words; more than MC_LEAN2X_COST values recomputed per
-// voxel on average means the pair has regions of large supports next to its texture -- the list is declared unusable (the overflow word)
-// and the passes go one per launch
-#ifndef MC_LEAN2X_COST
-#define MC_LEAN2X_COST 2.0f
-#endif
-__global__ void __launch_bounds__(256) cbca_list_cost_kernel(const LeanArgs A, int npl)
-{
-	__shared__ float wsum[4];
-	if (!cbca_gate(A.flags, A.route)) return;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const uint32_t *__restrict__ tab = A.hdr + A.cost_words + (size_t)blockIdx.x * npl;
-	float t = 0;
-	for (int i = tid; i < npl; i += 256) t += __uint_as_float(tab[i]);
-#pragma unroll
-	for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
-	if (lane == 0) wsum[wv] = t;
-	__syncthreads();
-	if (tid == 0 && !(wsum[0] + wsum[1] + wsum[2] + wsum[3] <= A.cost_limit * (float)A.H * (float)A.W)) A.hdr[LH_OVERFLOW] = 1u;
 }
 
 // counts of a plane's waves -> slot numbers: wave table word 0 = slot + 1 of the wave's first entry (0: none).  One block per plane,
@@ -548,26 +497,57 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
 
 // ---- two passes in one launch ---------------------------------------------------------------------------------------------------
 // mc_predict aggregates a volume 2 + 16 times in a row (main.lua:998-1001, 1033-1039), and on a texture each pass is a 3 x 3 stencil
-// that moves the whole volume through HBM.  This kernel runs TWO consecutive passes per launch: a wave reads R + 4 rows of 256 columns
-// of the plane, computes the R + 2 rows of the FIRST pass it needs (kept on chip: an LDS tile of its own, no barrier -- the LDS serves a
-// wave's instructions in order), then its R x 252 outputs of the SECOND pass -- the plane is read 1.5 x and written once per two passes
-// instead of read 2.5 x and written twice.  Both passes do, per output, exactly what cbca_lean_kernel does (nine additions in the
-// reference's order, adcensus.cu:356-373, the division by 9, copy-through without a partner).
+// that moves the whole volume through HBM.  cbca_lean2x_kernel runs TWO consecutive passes per launch: a wave reads R + 4 rows of 256
+// columns of the plane, computes the R + 2 rows of the FIRST pass it needs (kept on chip: an LDS tile of its own, no barrier -- the LDS
+// serves a wave's instructions in order), then its R x 252 outputs of the SECOND pass -- the plane is read 1.5 x and written once per
+// two passes instead of read 2.5 x and written twice.  Both passes do, per output, exactly what cbca_lean_kernel does (the additions of
+// the reference in its order, adcensus.cu:356-373, the division by 9, copy-through without a partner).
 //
-// The listed outputs (supports that are not the minimal 3 x 3; cbca_classify_kernel with this kernel's geometry: the wave's R + 2
-// first-pass rows, columns 1 .. 254 of its 256) are redone by one lane per entry with the reference's loop:
-//   first pass   out of the input plane (list_entry_value, as in cbca_lean_kernel), the value replaces the tile's;
+// The listed outputs (supports that are not the minimal 3 x 3) of the wave's R + 2 first-pass rows, columns 1 .. 254 of its 256, are
+// written once per pair and direction by cbca_classify2x_kernel into the wave's RECORD -- a fixed 4 KB of the plan area: 16 bytes
+// {entries, cost, -, -} and 255 slots of 16 bytes (voxel, shape; the entry format of the single-pass list) -- so that the first 64
+// entries are requested together with the rows, without a table lookup in front (a short-lived wave's time is its chain of dependent
+// memory round trips, not its instructions: the first version, with the single-pass kernel's wave table -> slots -> values chain, a
+// chain of arm lookups per value outside the tile and the listed outputs stored behind the rows' stores, took 1.08 ms per launch with
+// 85 as with 58 vector instructions per row).  One lane per entry redoes the reference's loop:
+//   first pass   out of the input plane (as in cbca_lean_kernel), the value replaces the tile's;
 //   second pass  (entries among the wave's own R x 252 outputs) over the first pass's values: out of the tile where the support lies
-//                inside it, and for the values outside (supports that reach over the tile's edge: arms >= 2 next to it) the first
-//                pass's value is recomputed from the input plane on the spot (first_pass_value) -- the same additions in the same order.
+//                inside it; a value outside (supports that reach over the tile's edge: arms >= 2 next to it) is recomputed from the
+//                input plane on the spot (first_pass_value) -- the same additions in the same order.  The results replace the tile's
+//                rows before they are stored (up to 64 entries; beyond, they are stored behind the rows' stores).
+// A wave with more than 255 entries, or a plane whose second-pass entries would recompute more than cost_limit values per voxel
+// (cbca_list_cost_kernel), makes the list unusable: the pair is not the texture this path is for, and the passes go one per launch.
 // Columns: a wave's 256 columns start at 252 strip - 2; lanes 0 and 63 hold two outer columns each whose values are incomplete
 // (no neighbour) and store only their two inner ones.
+constexpr int L2X_REC_WORDS = 1024;   // a wave's record: 4 words of head + 255 slots of 4 words
+constexpr int L2X_SLOTS = 255;
+
+// first-pass value of pixel (yy, xx) of this plane, from the input plane.  The common case on a texture -- the minimal 3 x 3 support -- is
+// requested together with the arm lengths that decide it (one round trip); anything else walks the support with the reference's loop.
 __device__ __forceinline__ float first_pass_value(const LeanArgs &A, const __amdgpu_buffer_rsrc_t &rv, int sh, int yy, int xx)
 {
-	const int W = A.W;
+	const int W = A.W, H = A.H;
 	const int g = yy * W + xx;
+	const cb_u32 OOB = 0x80000000u;
 	if (xx + sh < 0 || xx + sh >= W) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, (cb_u32)g * 4u, 0, 0));   // adcensus.cu:353-354
+	const bool inner = yy >= 1 && yy + 1 < H && xx >= 1 && xx + 1 < W;
+	const int gu = inner ? g - W : g, gd = inner ? g + W : g;
 	const uint32_t mm = bytemin4(A.p0[g], A.p1[g + sh]);
+	const uint32_t mu = bytemin4(A.p0[gu], A.p1[gu + sh]), md = bytemin4(A.p0[gd], A.p1[gd + sh]);
+	float r0[3], r1[3], r2[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		r0[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, inner ? (cb_u32)(g - W - 1 + k) * 4u : OOB, 0, 0));
+		r1[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, inner ? (cb_u32)(g - 1 + k) * 4u : OOB, 0, 0));
+		r2[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, inner ? (cb_u32)(g + W - 1 + k) * 4u : OOB, 0, 0));
+	}
+	if (inner && mm == 0x01010101u && (mu & 0xffffu) == 0x0101u && (md & 0xffffu) == 0x0101u) {
+		float t = 0;
+		t += r0[0]; t += r0[1]; t += r0[2];
+		t += r1[0]; t += r1[1]; t += r1[2];
+		t += r2[0]; t += r2[1]; t += r2[2];
+		return t / 9.0f;
+	}
 	const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
 	float sum = 0;
 	int cnt = 0;
@@ -648,7 +628,7 @@ __device__ __forceinline__ Row6 with_neighbours(const cb_f4 &v)
 // everything else the three-operation division does not cover: there the chain is redone from +0.0.  So the common path adds eight times.
 __device__ __forceinline__ cb_f4 lean_row(const Row6 &a, const Row6 &b, const Row6 &c, cb_u32 inr, bool allin)
 {
-	float sum[4], res[4];
+	float res[4];
 	bool fast = true;
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
@@ -656,7 +636,6 @@ __device__ __forceinline__ cb_f4 lean_row(const Row6 &a, const Row6 &b, const Ro
 		t += a.c[j + 2];
 		t += b.c[j]; t += b.c[j + 1]; t += b.c[j + 2];
 		t += c.c[j]; t += c.c[j + 1]; t += c.c[j + 2];
-		sum[j] = t;
 		fast = fast && div9_ok(t);
 		res[j] = div9(t);
 	}
@@ -694,13 +673,17 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 	const int xs = xb + 4 * lane;
 	const cb_u32 OOB = 0x80000000u;
 	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
+	// the wave's record: its first 64 entries are requested before the rows (loads return in order: they are here first), the count beside them
+	const uint32_t *__restrict__ rec = A.hdr + LH_WORDS + (size_t)w * L2X_REC_WORDS;
+	const cb_u4 ent = *(const cb_u4 *)(rec + 4 + 4 * lane);
+	const cb_u32 nent = min((cb_u32)__builtin_amdgcn_readfirstlane((int)rec[0]), (cb_u32)L2X_SLOTS);
 	cb_u32 inr = 0;   // bit j: the output has a partner (adcensus.cu:353)
 #pragma unroll
 	for (int j = 0; j < 4; ++j)
 		if (xs + j + sh >= 0 && xs + j + sh < W) inr |= 1u << j;
 	// input rows y0 - 2 .. y0 + R + 1, all requested before the first is used; rows outside the image: zeros.  The first strip's lane 0
-	// starts two pixels before its row: the previous row's last two -- never an operand of an output that is not listed -- except in
-	// row 0, where that offset lies before the plane: its two real columns come from a load of their own (fx).
+	// starts two pixels before its row: the previous row's last two -- never an operand of an output that is not listed -- except where
+	// that offset lies before the plane (row 0; row 1 of an image one pixel wide): those rows' two real columns come from loads of their own.
 	cb_u4 v[R + 4];
 #pragma unroll
 	for (int k = 0; k < R + 4; ++k) {
@@ -708,16 +691,21 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 		const bool ok = (unsigned)r < (unsigned)H && xs < W && r * W + xs >= 0;
 		v[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (cb_u32)(r * W + xs) * 4u : OOB, 0, 0);
 	}
-	// (xs = -2, rows 0 and -- images one pixel wide -- 1: the row's columns 0 and 1 are the plane's words r W and r W + 1)
 	const bool edge0 = y0 == 0 && xs < 0 && 0 < H, edge1 = y0 == 0 && xs < 0 && W + xs < 0 && 1 < H;
 	const cb_u2 fx0 = __builtin_amdgcn_raw_buffer_load_b64(rv, edge0 ? 0u : OOB, 0, 0);
 	const cb_u2 fx1 = __builtin_amdgcn_raw_buffer_load_b64(rv, edge1 ? (cb_u32)W * 4u : OOB, 0, 0);
-	// the wave's entries: its words of the wave table
-	const uint32_t *__restrict__ slots = A.hdr + A.slots_words;
-	const cb_u32 seg = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w]);   // slot + 1 of the wave's first entry
-	cb_u32 nent = (cb_u32)__builtin_amdgcn_readfirstlane((int)A.hdr[A.wtab_words + 2 * w + 1]);
-	if (seg == 0 || seg > A.cap) nent = 0;
-	else nent = min(nent, A.cap - (seg - 1));
+	// the entries' positions; the runs of the small-class ones (at most four rows of at most four values: nearly all of a texture's
+	// entries) are requested now, behind the rows: lines this wave and its neighbours are fetching anyway
+	const bool ehas = (cb_u32)lane < nent;
+	const cb_u32 erem = ent.x - (cb_u32)d * (cb_u32)HWi;   // y * W + x
+	const int ey = (int)(erem / (cb_u32)W), ex = (int)erem - ey * W;
+	const int ery = ey - (y0 - 1), ecx = ex - xb;
+	const bool e1 = ehas && erem < (cb_u32)HWi && (unsigned)ery < (unsigned)(R + 2) && (unsigned)ecx < 256u;   // a first-pass entry of this tile
+	const bool e2 = e1 && ey >= y0 && ey < y1 && (unsigned)(ecx - 2) < 252u;                                   // ... also one of the wave's own outputs
+	const bool esmall = e1 && (ent.y & 0xf0u) == 0xe0u;
+	cb_u4 ev[4];
+	int enn[4];
+	small_request(A, rv, esmall, ent, erem, ev, enn);
 	if (edge0) { v[2].z = fx0.x; v[2].w = fx0.y; }
 	if (edge1) { v[3].z = fx1.x; v[3].w = fx1.y; }
 	const bool allin = __all(inr == 15u);
@@ -734,10 +722,11 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 		}
 	}
 	// ... its listed outputs, out of the input plane
-	for (cb_u32 i = (cb_u32)lane; i < nent; i += 64) {
-		const cb_u4 e = *(const cb_u4 *)(slots + (size_t)(seg - 1 + i) * 4);
-		const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;   // y * W + x
-		if (rem >= (cb_u32)HWi) continue;   // (not this plane's: never written by cbca_classify_kernel)
+	if (e1) T[ery * 256 + ecx] = esmall ? small_sum(ev, enn) : list_entry_value(A, rv, d, ent, erem);
+	for (cb_u32 i = 64u + (cb_u32)lane; i < nent; i += 64) {
+		const cb_u4 e = *(const cb_u4 *)(rec + 4 + 4 * i);
+		const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;
+		if (rem >= (cb_u32)HWi) continue;
 		const int y = (int)(rem / (cb_u32)W), x = (int)rem - y * W;
 		const int ry = y - (y0 - 1), cx = x - xb;
 		if ((unsigned)ry >= (unsigned)(R + 2) || (unsigned)cx >= 256u) continue;
@@ -748,32 +737,54 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
 	// second pass: the wave's R rows out of the tile
-	cb_f4 m[R + 2];
+	cb_f4 res[R];
+	{
+		cb_f4 m[R + 2];
 #pragma unroll
-	for (int k = 0; k < R + 2; ++k) m[k] = *(const cb_f4 *)(T + k * 256 + 4 * lane);
+		for (int k = 0; k < R + 2; ++k) m[k] = *(const cb_f4 *)(T + k * 256 + 4 * lane);
+		Row6 ma = with_neighbours(m[0]), mb = with_neighbours(m[1]);
+#pragma unroll
+		for (int k = 0; k < R; ++k) {
+			const Row6 mc = with_neighbours(m[k + 2]);
+			res[k] = lean_row(ma, mb, mc, inr, allin);
+			ma = mb; mb = mc;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	// ... its listed outputs, over the first pass's values.  Up to 64 entries (one per lane, nearly every wave of a texture): their values
+	// replace the rows' in the tile -- whose first-pass values nobody needs any more -- and the rows are stored from there; more: the rows
+	// are stored first and the entries' values behind them, once those stores have completed (the same addresses, written by other lanes)
+	const bool through_tile = nent <= 64u;
+	if (through_tile && nent) {
+		float val2 = 0;
+		if (e2) val2 = second_pass_entry<R>(A, rv, T, d, ent, erem, ey, ex, y0, xb);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();   // (every lane's reads of first-pass values are done)
+#pragma unroll
+		for (int k = 0; k < R; ++k) *(cb_f4 *)(T + k * 256 + 4 * lane) = res[k];
+		if (e2) T[(ey - y0) * 256 + ecx] = val2;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+		for (int k = 0; k < R; ++k) res[k] = *(const cb_f4 *)(T + k * 256 + 4 * lane);
+	}
 	const bool edge = lane == 0 || lane == 63;
 	const int xe = lane == 0 ? xs + 2 : xs;   // first of an edge lane's two stored columns
-	Row6 ma = with_neighbours(m[0]), mb = with_neighbours(m[1]);
 #pragma unroll
 	for (int k = 0; k < R; ++k) {
 		const int yo = y0 + k;
-		const Row6 mc = with_neighbours(m[k + 2]);
-		const cb_f4 res = lean_row(ma, mb, mc, inr, allin);
-		ma = mb; mb = mc;
 		const bool myrow = yo < y1;
 		const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vout + (size_t)d * HWi), 0, myrow ? (yo + 1) * W * 4 : 0, 0x00020000);
-		__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res.x), __float_as_uint(res.y), __float_as_uint(res.z), __float_as_uint(res.w)},
+		__builtin_amdgcn_raw_buffer_store_b128(cb_u4{__float_as_uint(res[k].x), __float_as_uint(res[k].y), __float_as_uint(res[k].z), __float_as_uint(res[k].w)},
 		                                       rrow, (myrow && !edge && xs < W) ? (cb_u32)(yo * W + xs) * 4u : OOB, 0, 0);
-		const cb_u2 two = lane == 0 ? cb_u2{__float_as_uint(res.z), __float_as_uint(res.w)} : cb_u2{__float_as_uint(res.x), __float_as_uint(res.y)};
+		const cb_u2 two = lane == 0 ? cb_u2{__float_as_uint(res[k].z), __float_as_uint(res[k].w)} : cb_u2{__float_as_uint(res[k].x), __float_as_uint(res[k].y)};
 		__builtin_amdgcn_raw_buffer_store_b64(two, rrow, (myrow && edge && xe >= 0 && xe < W) ? (cb_u32)(yo * W + xe) * 4u : OOB, 0, 0);
-		__builtin_amdgcn_sched_barrier(0);
 	}
-	// ... its listed outputs: over the first pass's values; their stores after the wave's own stores have completed (the same addresses,
-	// written by other lanes)
-	if (nent) {
+	if (!through_tile) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		for (cb_u32 i = (cb_u32)lane; i < nent; i += 64) {
-			const cb_u4 e = *(const cb_u4 *)(slots + (size_t)(seg - 1 + i) * 4);
+			const cb_u4 e = *(const cb_u4 *)(rec + 4 + 4 * i);
 			const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;
 			if (rem >= (cb_u32)HWi) continue;
 			const int y = (int)(rem / (cb_u32)W), x = (int)rem - y * W;
@@ -781,6 +792,138 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 			A.vout[(size_t)d * HWi + rem] = second_pass_entry<R>(A, rv, T, d, e, rem, y, x, y0, xb);
 		}
 	}
+}
+
+// once per pair and direction: every wave of cbca_lean2x_kernel lists, in its record, the outputs of its R + 2 first-pass rows (columns
+// 1 .. 254 of its 256) whose support is not the minimal 3 x 3 -- the test of cbca_classify_kernel -- with the support's shape, and what
+// its second-pass entries (those among its own outputs) cost beyond their own supports: a first-pass value outside the wave's tile is
+// recomputed at the price of its own support, estimated as (values outside the tile) x (values of the entry's support).
+__global__ void __launch_bounds__(256) cbca_classify2x_kernel(const LeanArgs A)
+{
+	__shared__ cb_u32 bufs[4][512];
+	if (!cbca_gate(A.flags, A.route)) return;
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	cb_u32 *__restrict__ buf = bufs[wv];
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // (the overflow word: zeroed before the launch, raised below and by cbca_list_cost_kernel)
+		A.hdr[LH_D] = (uint32_t)A.D; A.hdr[LH_H] = (uint32_t)A.H; A.hdr[LH_W] = (uint32_t)A.W;
+		A.hdr[LH_DIR] = (uint32_t)(A.direction + 1); A.hdr[LH_RB] = A.rbcode; A.hdr[LH_MAGIC] = LH_MAGIC_VALUE;
+	}
+	long long w;
+	int d, y0, y1, xb;
+	if (!lean_wave(A, wv, w, d, y0, y1, xb)) return;
+	const int H = A.H, W = A.W;
+	const int HWi = H * W;
+	const int sh = d * A.direction;
+	const int xs = xb + 4 * lane;
+	const cb_u32 OOB = 0x80000000u;
+	uint32_t *__restrict__ rec = A.hdr + LH_WORDS + (size_t)w * L2X_REC_WORDS;
+	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
+	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
+	cb_u32 want = 0;   // bit j: the column exists, has a partner (adcensus.cu:353) and is one of the tile's columns 1 .. 254
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+		if (xs + j >= 0 && xs + j < W && xs + j + sh >= 0 && xs + j + sh < W && (unsigned)(4 * lane + j - 1) < 254u) want |= 1u << j;
+	// combined lengths of row r for this lane's four columns (rows outside the image: 0 = "not the unit arm")
+	auto fetch = [&](int r, cb_u32 (&m)[4]) {
+		const bool rok = r >= 0 && r < H;
+		const int base = r * W + xs;
+		const cb_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rp0, rok ? (cb_u32)(base + CS_PAD) * 4u : OOB, 0, 0);
+		const cb_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rp1, rok ? (cb_u32)(base + sh + CS_PAD) * 4u : OOB, 0, 0);
+		m[0] = bytemin4(a.x, b.x); m[1] = bytemin4(a.y, b.y); m[2] = bytemin4(a.z, b.z); m[3] = bytemin4(a.w, b.w);
+	};
+	int cnt = 0;         // entries waiting in LDS
+	cb_u32 written = 0;  // entries already in the record (or dropped: more than the record holds)
+	float cost = 0;
+	auto flush = [&]() {
+		for (int i = lane; i < cnt; i += 64) {
+			const cb_u32 idx = buf[i];
+			const int rem = (int)(idx - (cb_u32)d * (cb_u32)HWi);   // y * W + x
+			const uint32_t mm = bytemin4(A.p0[rem], A.p1[rem + sh]);
+			const int u = (int)((mm >> 16) & 0xffu), dn = (int)(mm >> 24);
+			const int rows = u + dn + 1;
+			bool fits = u <= 13 && dn <= 13 && rows <= 11;
+			bool small = rows <= 4;   // at most four rows of at most four values
+			cb_u32 ew[3] = {0u, 0u, 0u};
+			const int ye = rem / W, xe = rem - ye * W;
+			const bool own = ye >= y0 && ye < y1 && (unsigned)(xe - xb - 2) < 252u;
+			float taps = 0, outside = 0;
+			for (int k = 0; k < rows && (fits || own); ++k) {
+				const int g = rem + (k - u) * W;
+				const uint32_t m = bytemin4(A.p0[g], A.p1[g + sh]);
+				const cb_u32 l = m & 0xffu, r = (m >> 8) & 0xffu;
+				if (own) {
+					const int ry = ye + k - u - (y0 - 1);
+					int in = 0;
+					if ((unsigned)ry < (unsigned)(A.rb + 2)) in = max(0, min(xe + (int)r, xb + 254) - max(xe - (int)l, xb + 1) + 1);
+					taps += (float)(l + r + 1u);
+					outside += (float)((int)(l + r + 1u) - in);
+				}
+				if (fits) {
+					fits = l <= 15u && r <= 15u;
+					small = small && l + r <= 3u;
+					const int j = 1 + k;
+					const cb_u32 byte = (l | (r << 4)) << ((j & 3) * 8);
+					if (j < 4) ew[0] |= byte; else if (j < 8) ew[1] |= byte; else ew[2] |= byte;
+				}
+			}
+			cost += outside * taps;
+			if (!fits) { ew[0] = 0xffu; ew[1] = ew[2] = 0u; }
+			else ew[0] |= small ? (0xe0u | (cb_u32)u | ((cb_u32)dn << 2)) : (cb_u32)(u | (dn << 4));
+			if (written + (cb_u32)i < (cb_u32)L2X_SLOTS) *(cb_u4 *)(rec + 4 + 4 * (size_t)(written + i)) = cb_u4{idx, ew[0], ew[1], ew[2]};
+		}
+		written += (cb_u32)cnt;
+		cnt = 0;
+	};
+	cb_u32 ma[4], mb[4], mc_[4], md[4];   // rows y - 1, y, y + 1 and, on its way, y + 2
+	const int ya = y0 - 1, yb = y1 + 1;   // the tile's first-pass rows (those inside the image)
+	fetch(ya - 1, ma);
+	fetch(ya, mb);
+	fetch(ya + 1, mc_);
+	for (int y = ya; y < yb; ++y) {
+		fetch(y + 2 <= yb ? y + 2 : -1, md);
+		const bool rowin = (unsigned)y < (unsigned)H;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const bool minimal = mb[j] == 0x01010101u && (ma[j] & 0xffffu) == 0x0101u && (mc_[j] & 0xffffu) == 0x0101u;
+			const bool listed = rowin && ((want >> j) & 1u) && !minimal;
+			const unsigned long long bal = __ballot(listed);
+			const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((cb_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)bal, 0));
+			if (listed) buf[pos] = (cb_u32)d * (cb_u32)HWi + (cb_u32)(y * W + xs + j);
+			cnt += __builtin_popcountll(bal);
+		}
+		if (cnt >= 256) flush();   // (a row adds at most 256 entries: 512 always hold them)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { ma[j] = mb[j]; mb[j] = mc_[j]; mc_[j] = md[j]; }
+	}
+	if (cnt) flush();
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) cost += __shfl_xor(cost, o);
+	if (lane == 0) {
+		*(cb_u4 *)rec = cb_u4{written, __float_as_uint(cost), 0u, 0u};
+		if (written > (cb_u32)L2X_SLOTS) A.hdr[LH_OVERFLOW] = 1u;
+	}
+}
+
+// ... after it: one block per plane adds the plane's waves' costs; more than cost_limit values recomputed per voxel on average means the
+// pair has regions of large supports next to its texture -- the list is declared unusable (the overflow word)
+#ifndef MC_LEAN2X_COST
+#define MC_LEAN2X_COST 2.0f
+#endif
+__global__ void __launch_bounds__(256) cbca_list_cost_kernel(const LeanArgs A, int npl)
+{
+	__shared__ float wsum[4];
+	if (!cbca_gate(A.flags, A.route)) return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t *__restrict__ recs = A.hdr + LH_WORDS + (size_t)blockIdx.x * npl * L2X_REC_WORDS;
+	float t = 0;
+	for (int i = tid; i < npl; i += 256) t += __uint_as_float(recs[(size_t)i * L2X_REC_WORDS + 1]);
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+	if (lane == 0) wsum[wv] = t;
+	__syncthreads();
+	if (tid == 0 && !(wsum[0] + wsum[1] + wsum[2] + wsum[3] <= A.cost_limit * (float)A.H * (float)A.W)) A.hdr[LH_OVERFLOW] = 1u;
 }
 
 // rows per wave / launch variant mc_predict uses (cfg.lean_rb = 0 / cfg.lean_variant < 0): measured at 1000 x 1500 x 256, one box
@@ -808,7 +951,7 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	A.vin = vin; A.vout = vout;
 	A.hdr = (uint32_t *)plan;
 	A.D = D; A.H = H; A.W = W; A.direction = direction;
-	A.pitch = two_pass ? 252 : 256; A.xoff = two_pass ? -2 : 0; A.halo = two_pass ? 1 : 0;
+	A.pitch = two_pass ? 252 : 256; A.xoff = two_pass ? -2 : 0;
 	A.gx = (int)cdiv(W, A.pitch);
 	A.rb = two_pass ? lean2x_rows(rb) : lean_rows(rb);
 	A.rbcode = (cb_u32)A.rb | (two_pass ? 0x100u : 0u);
@@ -817,15 +960,15 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	A.gyb = (int)cdiv(A.gy, 8);
 	A.gx_rcp = (cb_u32)((((uint64_t)1 << 32) + A.gx - 1) / A.gx);
 	const int64_t waves = (int64_t)A.gx * A.gy * D;
-	// [header LH_WORDS | wave table: 2 words per wave, canonical order (plane, chunk, strip) | two-pass geometry: a cost word per wave |
-	//  slots: 16 bytes each, capd per plane]
+	// [header LH_WORDS | wave table: 2 words per wave, canonical order (plane, chunk, strip) | slots: 16 bytes each, capd per plane]
+	// (two-pass geometry: [header LH_WORDS | a record of L2X_REC_WORDS per wave]; capd = 0 where the records do not fit)
 	A.wtab_words = LH_WORDS;
-	A.cost_words = (uint32_t)(A.wtab_words + 2 * waves);
-	A.slots_words = (uint32_t)((A.cost_words + (two_pass ? waves : 0) + 3) / 4 * 4);
+	A.slots_words = (uint32_t)((A.wtab_words + 2 * waves + 3) / 4 * 4);
 	const int64_t room = (int64_t)plan_bytes / 4 - A.slots_words;
 	int64_t cap = std::max<int64_t>(0, std::min<int64_t>(room / 4, 0x3ffffff0));
 	if (cap_limit > 0) cap = std::min<int64_t>(cap, cap_limit);   // (test hook: a list that does not fit)
 	A.capd = (uint32_t)(cap / std::max(1, D));
+	if (two_pass) A.capd = ((int64_t)plan_bytes / 4 >= LH_WORDS + waves * L2X_REC_WORDS) ? (uint32_t)L2X_SLOTS : 0u;
 	A.cap = A.capd * (uint32_t)D;
 	A.flags = cs.flag;
 	A.route = route;
@@ -847,11 +990,18 @@ static dim3 lean_grid(const LeanArgs &A)
 	return dim3(per_plane, (unsigned)A.D);
 }
 
-bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes, bool two_pass)
+bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes, bool two_pass, int rb)
 {
 	if ((int64_t)D * H * W >= ((int64_t)1 << 32) || D > 65535) return false;   // (32-bit voxel indices in the entries; the plane is blockIdx.y)
-	const LeanArgs A = lean_args(nullptr, nullptr, plan_bytes, nullptr, nullptr, D, H, W, -1, 0, 0, 0, 0, two_pass);
+	const LeanArgs A = lean_args(nullptr, nullptr, plan_bytes, nullptr, nullptr, D, H, W, -1, 0, rb, 0, 0, two_pass);
 	return A.capd >= 2 && (int64_t)A.gx * A.gy < 65536 && (int64_t)A.gx * A.gy * D < ((int64_t)1 << 30);
+}
+
+// bytes of the plan area the two-pass records take at the product's rows per wave (small images: more than the tile kernel's plan)
+size_t cbca_lean2x_bytes(int D, int H, int W)
+{
+	const int64_t waves = (int64_t)cdiv(W, 252) * cdiv(H, lean2x_rows(0)) * D;
+	return (size_t)(LH_WORDS + waves * L2X_REC_WORDS) * 4;
 }
 
 // once per pair and direction (before the first pass): the list of outputs whose support is not the minimal 3 x 3
@@ -865,10 +1015,15 @@ int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int 
 		set_error("cbca_classify: %s", hipGetErrorString(e));
 		return (int)e;
 	}
+	if (two_pass) {   // (every wave writes its own record: one launch, + the per-plane cost check)
+		if (A.capd == 0) { set_error("cbca_classify: the plan area does not hold the two-pass records"); return MC_EINVAL; }
+		hipLaunchKernelGGL(cbca_classify2x_kernel, lean_grid(A), dim3(256), 0, st, A);
+		hipLaunchKernelGGL(cbca_list_cost_kernel, dim3((unsigned)D), dim3(256), 0, st, A, A.gx * A.gy);
+		return check_launch("cbca_classify (two-pass records)");
+	}
 	hipLaunchKernelGGL(cbca_classify_kernel<0>, lean_grid(A), dim3(256), 0, st, A);
 	hipLaunchKernelGGL(cbca_list_scan_kernel, dim3((unsigned)D), dim3(256), 0, st, A, A.gx * A.gy);
 	hipLaunchKernelGGL(cbca_classify_kernel<1>, lean_grid(A), dim3(256), 0, st, A);
-	if (two_pass) hipLaunchKernelGGL(cbca_list_cost_kernel, dim3((unsigned)D), dim3(256), 0, st, A, A.gx * A.gy);
 	return check_launch("cbca_classify");
 }
 

@@ -896,7 +896,8 @@ static PlanLayout plan_layout(int D, int H, int W)
 	L.total = L.ud + (size_t)D * H * L.wp;
 	return L;
 }
-size_t cbca_plan_bytes(int D, int H, int W) { return plan_layout(D, H, W).total; }
+size_t cbca_lean2x_bytes(int D, int H, int W);   // cbca_lean.hip: what the texture route's two-pass records take of the same area
+size_t cbca_plan_bytes(int D, int H, int W) { return std::max(plan_layout(D, H, W).total, cbca_lean2x_bytes(D, H, W)); }
 
 template <int A, int TW, int TH, int NWAVES, int MODE>
 static int cbca_tiles_launch_mode(CbcaArgs P, bool nt, hipStream_t st)
