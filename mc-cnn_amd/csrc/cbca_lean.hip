@@ -505,7 +505,8 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
 //
 // The listed outputs (supports that are not the minimal 3 x 3) of the wave's R + 2 first-pass rows, columns 1 .. 254 of its 256, are
 // written once per pair and direction by cbca_classify2x_kernel into the wave's RECORD -- a fixed 4 KB of the plan area: 16 bytes
-// {entries, cost, -, -} and 255 slots of 16 bytes (voxel, shape; the entry format of the single-pass list) -- so that the first 64
+// {entries, cost, -, -} and 255 slots of 16 bytes (voxel, shape; the entry format of the single-pass list; 256 more for the waves of the
+// image's first and last rows, all of whose outputs are listed) -- so that the first 64
 // entries are requested together with the rows, without a table lookup in front (a short-lived wave's time is its chain of dependent
 // memory round trips, not its instructions: the first version, with the single-pass kernel's wave table -> slots -> values chain, a
 // chain of arm lookups per value outside the tile and the listed outputs stored behind the rows' stores, took 1.08 ms per launch with
@@ -521,6 +522,27 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
 // (no neighbour) and store only their two inner ones.
 constexpr int L2X_REC_WORDS = 1024;   // a wave's record: 4 words of head + 255 slots of 4 words
 constexpr int L2X_SLOTS = 255;
+// The waves of an image's first and last row chunk hold a whole image row of entries (a border output's support is never the minimal one):
+// they get a second record of 256 slots, behind all the first ones -- per plane one row of them for the top chunks, one for the bottom ones.
+struct L2xRecords {
+	uint32_t *rec, *xrec;   // the wave's record; its second one (border chunks) or null
+	cb_u32 cap;             // entries the wave can hold
+};
+__device__ __forceinline__ L2xRecords l2x_records(const LeanArgs &A, long long w, int d, int y0, int y1, int xb)
+{
+	L2xRecords r;
+	r.rec = A.hdr + LH_WORDS + (size_t)w * L2X_REC_WORDS;
+	const int border = y0 == 0 ? 0 : (y1 == A.H ? 1 : -1);
+	const int strip = (xb - A.xoff) / A.pitch;
+	const size_t firsts = (size_t)A.gx * A.gy * A.D;
+	r.xrec = border >= 0 ? A.hdr + LH_WORDS + (firsts + ((size_t)d * 2 + border) * A.gx + strip) * L2X_REC_WORDS : nullptr;
+	r.cap = border >= 0 ? (cb_u32)(L2X_SLOTS + 256) : (cb_u32)L2X_SLOTS;
+	return r;
+}
+__device__ __forceinline__ uint32_t *l2x_slot(const L2xRecords &r, cb_u32 i)
+{
+	return i < (cb_u32)L2X_SLOTS ? r.rec + 4 + 4 * (size_t)i : r.xrec + 4 * (size_t)(i - (cb_u32)L2X_SLOTS);
+}
 
 // first-pass value of pixel (yy, xx) of this plane, from the input plane.  The common case on a texture -- the minimal 3 x 3 support -- is
 // requested together with the arm lengths that decide it (one round trip); anything else walks the support with the reference's loop.
@@ -674,9 +696,10 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 	const cb_u32 OOB = 0x80000000u;
 	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
 	// the wave's record: its first 64 entries are requested before the rows (loads return in order: they are here first), the count beside them
-	const uint32_t *__restrict__ rec = A.hdr + LH_WORDS + (size_t)w * L2X_REC_WORDS;
+	const L2xRecords rr = l2x_records(A, w, d, y0, y1, xb);
+	const uint32_t *__restrict__ rec = rr.rec;
 	const cb_u4 ent = *(const cb_u4 *)(rec + 4 + 4 * lane);
-	const cb_u32 nent = min((cb_u32)__builtin_amdgcn_readfirstlane((int)rec[0]), (cb_u32)L2X_SLOTS);
+	const cb_u32 nent = min((cb_u32)__builtin_amdgcn_readfirstlane((int)rec[0]), rr.cap);
 	cb_u32 inr = 0;   // bit j: the output has a partner (adcensus.cu:353)
 #pragma unroll
 	for (int j = 0; j < 4; ++j)
@@ -724,7 +747,7 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 	// ... its listed outputs, out of the input plane
 	if (e1) T[ery * 256 + ecx] = esmall ? small_sum(ev, enn) : list_entry_value(A, rv, d, ent, erem);
 	for (cb_u32 i = 64u + (cb_u32)lane; i < nent; i += 64) {
-		const cb_u4 e = *(const cb_u4 *)(rec + 4 + 4 * i);
+		const cb_u4 e = *(const cb_u4 *)l2x_slot(rr, i);
 		const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;
 		if (rem >= (cb_u32)HWi) continue;
 		const int y = (int)(rem / (cb_u32)W), x = (int)rem - y * W;
@@ -784,7 +807,7 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 	if (!through_tile) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		for (cb_u32 i = (cb_u32)lane; i < nent; i += 64) {
-			const cb_u4 e = *(const cb_u4 *)(rec + 4 + 4 * i);
+			const cb_u4 e = *(const cb_u4 *)l2x_slot(rr, i);
 			const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;
 			if (rem >= (cb_u32)HWi) continue;
 			const int y = (int)(rem / (cb_u32)W), x = (int)rem - y * W;
@@ -817,7 +840,8 @@ __global__ void __launch_bounds__(256) cbca_classify2x_kernel(const LeanArgs A)
 	const int sh = d * A.direction;
 	const int xs = xb + 4 * lane;
 	const cb_u32 OOB = 0x80000000u;
-	uint32_t *__restrict__ rec = A.hdr + LH_WORDS + (size_t)w * L2X_REC_WORDS;
+	const L2xRecords rr = l2x_records(A, w, d, y0, y1, xb);
+	uint32_t *__restrict__ rec = rr.rec;
 	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
 	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
@@ -871,7 +895,7 @@ __global__ void __launch_bounds__(256) cbca_classify2x_kernel(const LeanArgs A)
 			cost += outside * taps;
 			if (!fits) { ew[0] = 0xffu; ew[1] = ew[2] = 0u; }
 			else ew[0] |= small ? (0xe0u | (cb_u32)u | ((cb_u32)dn << 2)) : (cb_u32)(u | (dn << 4));
-			if (written + (cb_u32)i < (cb_u32)L2X_SLOTS) *(cb_u4 *)(rec + 4 + 4 * (size_t)(written + i)) = cb_u4{idx, ew[0], ew[1], ew[2]};
+			if (written + (cb_u32)i < rr.cap) *(cb_u4 *)l2x_slot(rr, written + (cb_u32)i) = cb_u4{idx, ew[0], ew[1], ew[2]};
 		}
 		written += (cb_u32)cnt;
 		cnt = 0;
@@ -902,7 +926,7 @@ __global__ void __launch_bounds__(256) cbca_classify2x_kernel(const LeanArgs A)
 	for (int o = 32; o >= 1; o >>= 1) cost += __shfl_xor(cost, o);
 	if (lane == 0) {
 		*(cb_u4 *)rec = cb_u4{written, __float_as_uint(cost), 0u, 0u};
-		if (written > (cb_u32)L2X_SLOTS) A.hdr[LH_OVERFLOW] = 1u;
+		if (written > rr.cap) A.hdr[LH_OVERFLOW] = 1u;
 	}
 }
 
@@ -968,7 +992,7 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	int64_t cap = std::max<int64_t>(0, std::min<int64_t>(room / 4, 0x3ffffff0));
 	if (cap_limit > 0) cap = std::min<int64_t>(cap, cap_limit);   // (test hook: a list that does not fit)
 	A.capd = (uint32_t)(cap / std::max(1, D));
-	if (two_pass) A.capd = ((int64_t)plan_bytes / 4 >= LH_WORDS + waves * L2X_REC_WORDS) ? (uint32_t)L2X_SLOTS : 0u;
+	if (two_pass) A.capd = ((int64_t)plan_bytes / 4 >= LH_WORDS + (waves + (int64_t)A.gx * 2 * D) * L2X_REC_WORDS) ? (uint32_t)L2X_SLOTS : 0u;
 	A.cap = A.capd * (uint32_t)D;
 	A.flags = cs.flag;
 	A.route = route;
@@ -1000,8 +1024,8 @@ bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes, bool two_pass, int r
 // bytes of the plan area the two-pass records take at the product's rows per wave (small images: more than the tile kernel's plan)
 size_t cbca_lean2x_bytes(int D, int H, int W)
 {
-	const int64_t waves = (int64_t)cdiv(W, 252) * cdiv(H, lean2x_rows(0)) * D;
-	return (size_t)(LH_WORDS + waves * L2X_REC_WORDS) * 4;
+	const int64_t waves = (int64_t)cdiv(W, 252) * cdiv(H, lean2x_rows(0)) * D, seconds = (int64_t)cdiv(W, 252) * 2 * D;
+	return (size_t)(LH_WORDS + (waves + seconds) * L2X_REC_WORDS) * 4;
 }
 
 // once per pair and direction (before the first pass): the list of outputs whose support is not the minimal 3 x 3
