@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256) cbca_list_kernel(const LeanArgs A)
 constexpr int L2X_REC_WORDS = 1024;   // a wave's record: 4 words of head + 255 slots of 4 words
 constexpr int L2X_SLOTS = 255;
 // The waves of an image's first and last row chunk hold a whole image row of entries (a border output's support is never the minimal one):
-// they get a second record of 256 slots, behind all the first ones -- per plane one row of them for the top chunks, one for the bottom ones.
+// they get a second record of 256 slots, behind all the first ones -- per plane one row of them for the top chunks, two for the bottom ones.
 struct L2xRecords {
 	uint32_t *rec, *xrec;   // the wave's record; its second one (border chunks) or null
 	cb_u32 cap;             // entries the wave can hold
@@ -532,10 +532,10 @@ __device__ __forceinline__ L2xRecords l2x_records(const LeanArgs &A, long long w
 {
 	L2xRecords r;
 	r.rec = A.hdr + LH_WORDS + (size_t)w * L2X_REC_WORDS;
-	const int border = y0 == 0 ? 0 : (y1 == A.H ? 1 : -1);
+	const int border = y0 == 0 ? 0 : (y1 == A.H ? 1 : (y1 == A.H - 1 ? 2 : -1));   // (2: the chunk above a last chunk of one row -- the image's last row is its tile's)
 	const int strip = (xb - A.xoff) / A.pitch;
 	const size_t firsts = (size_t)A.gx * A.gy * A.D;
-	r.xrec = border >= 0 ? A.hdr + LH_WORDS + (firsts + ((size_t)d * 2 + border) * A.gx + strip) * L2X_REC_WORDS : nullptr;
+	r.xrec = border >= 0 ? A.hdr + LH_WORDS + (firsts + ((size_t)d * 3 + border) * A.gx + strip) * L2X_REC_WORDS : nullptr;
 	r.cap = border >= 0 ? (cb_u32)(L2X_SLOTS + 256) : (cb_u32)L2X_SLOTS;
 	return r;
 }
@@ -992,7 +992,7 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	int64_t cap = std::max<int64_t>(0, std::min<int64_t>(room / 4, 0x3ffffff0));
 	if (cap_limit > 0) cap = std::min<int64_t>(cap, cap_limit);   // (test hook: a list that does not fit)
 	A.capd = (uint32_t)(cap / std::max(1, D));
-	if (two_pass) A.capd = ((int64_t)plan_bytes / 4 >= LH_WORDS + (waves + (int64_t)A.gx * 2 * D) * L2X_REC_WORDS) ? (uint32_t)L2X_SLOTS : 0u;
+	if (two_pass) A.capd = ((int64_t)plan_bytes / 4 >= LH_WORDS + (waves + (int64_t)A.gx * 3 * D) * L2X_REC_WORDS) ? (uint32_t)L2X_SLOTS : 0u;
 	A.cap = A.capd * (uint32_t)D;
 	A.flags = cs.flag;
 	A.route = route;
@@ -1024,7 +1024,7 @@ bool cbca_lean_fits(int D, int H, int W, size_t plan_bytes, bool two_pass, int r
 // bytes of the plan area the two-pass records take at the product's rows per wave (small images: more than the tile kernel's plan)
 size_t cbca_lean2x_bytes(int D, int H, int W)
 {
-	const int64_t waves = (int64_t)cdiv(W, 252) * cdiv(H, lean2x_rows(0)) * D, seconds = (int64_t)cdiv(W, 252) * 2 * D;
+	const int64_t waves = (int64_t)cdiv(W, 252) * cdiv(H, lean2x_rows(0)) * D, seconds = (int64_t)cdiv(W, 252) * 3 * D;
 	return (size_t)(LH_WORDS + (waves + seconds) * L2X_REC_WORDS) * 4;
 }
 
