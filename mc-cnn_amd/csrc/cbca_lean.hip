@@ -36,6 +36,7 @@ struct LeanArgs {
 	cb_u32 gx_rcp;               // ceil(2^32 / gx)
 	int order, gyb;              // wave order: 0 linear over the volume, 1 one band of gyb row chunks per XCD (blockIdx & 7), each swept linearly
 	int pitch, xoff;             // a wave's 256 columns start at strip * pitch + xoff (single pass: 256, 0; two passes in one launch: 252, -2)
+	int wpb;                     // waves per block of the launch (4; cbca_lean2x_kernel: L2X_WPB)
 	cb_u32 rbcode;               // header word LH_RB of a list of this geometry: rb, + 0x100 for the two-pass geometry
 	const uint32_t *flags;       // cbca_pack's flag words
 	int route;
@@ -74,7 +75,7 @@ __device__ __forceinline__ bool lean_runs(const LeanArgs &A)
 __device__ __forceinline__ bool lean_wave(const LeanArgs &A, int wv, long long &w, int &d, int &y0, int &y1, int &x0)
 {
 	d = (int)blockIdx.y;
-	const cb_u32 lw = (A.order == 1 ? (blockIdx.x >> 3) : blockIdx.x) * 4u + (cb_u32)wv;
+	const cb_u32 lw = (A.order == 1 ? (blockIdx.x >> 3) : blockIdx.x) * (cb_u32)A.wpb + (cb_u32)wv;
 	const cb_u32 t = A.gx == 1 ? lw : __umulhi(lw, A.gx_rcp);   // lw / gx (exact for lw < 2^16: gx_rcp = ceil(2^32 / gx), gx >= 2)
 	const int strip = (int)(lw - t * (cb_u32)A.gx);
 	int chunk = (int)t;
@@ -678,10 +679,119 @@ __device__ __forceinline__ cb_f4 lean_row(const Row6 &a, const Row6 &b, const Ro
 	return cb_f4{res[0], res[1], res[2], res[3]};
 }
 
-template <int R>
-__global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
+// first-pass values of the n <= 4 pixels (yy, xx0 .. xx0 + n - 1) of this plane, from the input plane: a support row of a second-pass entry
+// that lies outside the wave's tile.  The common case on a texture -- all of them with the minimal 3 x 3 support -- out of ONE round trip:
+// three rows of six values and the arm lengths that decide it are requested together; anything else pixel by pixel (first_pass_value).
+__device__ __forceinline__ void first_pass_row(const LeanArgs &A, const __amdgpu_buffer_rsrc_t &rv, const __amdgpu_buffer_rsrc_t &rp0,
+                                               const __amdgpu_buffer_rsrc_t &rp1, int sh, int yy, int xx0, int n, float (&out)[4])
 {
-	__shared__ __attribute__((aligned(16))) float tiles[4][(R + 2) * 256];
+	const int W = A.W, H = A.H;
+	const cb_u32 OOB = 0x80000000u;
+	const int g0 = yy * W + xx0;
+	const bool vec = yy >= 1 && yy + 1 < H && xx0 >= 1 && xx0 + n < W && xx0 + sh >= 0 && xx0 + n - 1 + sh < W;   // inside the image with a ring around, partners for all
+	cb_u4 a[3], b[3], lo[3];
+	cb_u2 hi[3];
+#pragma unroll
+	for (int q = 0; q < 3; ++q) {
+		const int g = g0 + (q - 1) * W;
+		a[q] = __builtin_amdgcn_raw_buffer_load_b128(rp0, vec ? (cb_u32)(g + CS_PAD) * 4u : OOB, 0, 0);
+		b[q] = __builtin_amdgcn_raw_buffer_load_b128(rp1, vec ? (cb_u32)(g + sh + CS_PAD) * 4u : OOB, 0, 0);
+		lo[q] = __builtin_amdgcn_raw_buffer_load_b128(rv, vec ? (cb_u32)(g - 1) * 4u : OOB, 0, 0);
+		hi[q] = __builtin_amdgcn_raw_buffer_load_b64(rv, vec ? (cb_u32)(g + 3) * 4u : OOB, 0, 0);
+	}
+	const cb_u32 au[4] = {a[0].x, a[0].y, a[0].z, a[0].w}, bu[4] = {b[0].x, b[0].y, b[0].z, b[0].w};
+	const cb_u32 am[4] = {a[1].x, a[1].y, a[1].z, a[1].w}, bm[4] = {b[1].x, b[1].y, b[1].z, b[1].w};
+	const cb_u32 ad[4] = {a[2].x, a[2].y, a[2].z, a[2].w}, bd[4] = {b[2].x, b[2].y, b[2].z, b[2].w};
+	bool allmin = vec;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const bool minimal = bytemin4(am[c], bm[c]) == 0x01010101u && (bytemin4(au[c], bu[c]) & 0xffffu) == 0x0101u && (bytemin4(ad[c], bd[c]) & 0xffffu) == 0x0101u;
+		allmin = allmin && (c >= n || minimal);
+	}
+	if (allmin) {
+		float r[3][6];
+#pragma unroll
+		for (int q = 0; q < 3; ++q) {
+			r[q][0] = __uint_as_float(lo[q].x); r[q][1] = __uint_as_float(lo[q].y); r[q][2] = __uint_as_float(lo[q].z); r[q][3] = __uint_as_float(lo[q].w);
+			r[q][4] = __uint_as_float(hi[q].x); r[q][5] = __uint_as_float(hi[q].y);
+		}
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			float t = 0;
+			t += r[0][c]; t += r[0][c + 1]; t += r[0][c + 2];
+			t += r[1][c]; t += r[1][c + 1]; t += r[1][c + 2];
+			t += r[2][c]; t += r[2][c + 1]; t += r[2][c + 2];
+			out[c] = t / 9.0f;
+		}
+	} else {
+		for (int c = 0; c < n; ++c) {
+			const float t = first_pass_value(A, rv, sh, yy, xx0 + c);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) out[j] = j == c ? t : out[j];
+		}
+	}
+}
+
+// second-pass value of a small-class entry (at most four rows of at most four values: nearly all of a texture's entries): the rows inside
+// the tile are read at once, a row outside it is recomputed as a row (first_pass_row), then the reference's additions in their order
+template <int R>
+__device__ __forceinline__ float second_pass_small(const LeanArgs &A, const __amdgpu_buffer_rsrc_t &rv, const __amdgpu_buffer_rsrc_t &rp0,
+                                                   const __amdgpu_buffer_rsrc_t &rp1, const float *__restrict__ T, int sh, bool on, const cb_u4 &e,
+                                                   int y, int x, int y0, int xb)
+{
+	const cb_u32 b0 = e.y & 0xffu;
+	const int u = (int)(b0 & 3u), rows = on ? u + (int)((b0 >> 2) & 3u) + 1 : 0;
+	float t[4][4];
+	int nn[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const cb_u32 lr = entry_byte(e, 1 + k);
+		const int l = (int)(lr & 15u);
+		nn[k] = k < rows ? l + (int)(lr >> 4) + 1 : 0;
+		const int yy = y + k - u, ry = yy - (y0 - 1), cx0 = x - l - xb;
+		const bool inside = (unsigned)ry < (unsigned)(R + 2) && cx0 >= 1 && cx0 + nn[k] - 1 <= 254;
+		const int base = inside ? ry * 256 + cx0 : 0;
+#pragma unroll
+		for (int c = 0; c < 4; ++c) t[k][c] = T[c < nn[k] ? base + c : 0];
+		const bool need = nn[k] > 0 && !inside;
+		if (__any(need)) {
+			if (need) first_pass_row(A, rv, rp0, rp1, sh, yy, x - l, nn[k], t[k]);
+		}
+	}
+	float sum = 0;
+	int cnt = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+#pragma unroll
+		for (int c = 0; c < 4; ++c) sum += c < nn[k] ? t[k][c] : -0.0f;
+		cnt += nn[k];
+	}
+	return sum / (float)cnt;
+}
+
+#ifndef MC_LEAN2X_WPB
+#define MC_LEAN2X_WPB 2
+#endif
+constexpr int L2X_WPB = MC_LEAN2X_WPB;   // waves per block: 10 KB of LDS per wave (R = 8); blocks of two waves fill a CU's 160 KB in finer steps than blocks of four
+
+// a listed output of the wave's tile, from its record entry (word 0 = first-pass row | column << 8)
+struct L2xEntry { int ry, cx, y, x; cb_u32 rem; bool first, own; };
+template <int R>
+__device__ __forceinline__ L2xEntry l2x_entry(const cb_u4 &e, bool has, int y0, int y1, int xb, int W)
+{
+	L2xEntry t;
+	t.ry = (int)(e.x & 0xffu); t.cx = (int)(e.x >> 8);
+	t.y = y0 - 1 + t.ry; t.x = xb + t.cx;
+	t.rem = (cb_u32)(t.y * W + t.x);
+	t.first = has && t.ry < R + 2 && (unsigned)t.cx < 256u;                                         // (written by cbca_classify2x_kernel: inside the image)
+	t.own = t.first && t.y >= y0 && t.y < y1 && (unsigned)(t.cx - 2) < 252u;                        // ... also one of the wave's own outputs
+	return t;
+}
+
+template <int R, int WPB>
+__global__ void __launch_bounds__(64 * WPB) cbca_lean2x_kernel(const LeanArgs A)
+{
+	__shared__ __attribute__((aligned(16))) float tiles[WPB][(R + 2) * 256];
 	if (!lean_runs(A)) return;
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -695,6 +805,9 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 	const int xs = xb + 4 * lane;
 	const cb_u32 OOB = 0x80000000u;
 	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(A.vin + (size_t)d * HWi), 0, HWi * 4, 0x00020000);
+	const int padded_bytes = (HWi + 2 * CS_PAD) * 4;
+	const __amdgpu_buffer_rsrc_t rp0 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p0 - CS_PAD), 0, padded_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc((void *)(A.p1 - CS_PAD), 0, padded_bytes, 0x00020000);
 	// the wave's record: its first 64 entries are requested before the rows (loads return in order: they are here first), the count beside them
 	const L2xRecords rr = l2x_records(A, w, d, y0, y1, xb);
 	const uint32_t *__restrict__ rec = rr.rec;
@@ -717,18 +830,13 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 	const bool edge0 = y0 == 0 && xs < 0 && 0 < H, edge1 = y0 == 0 && xs < 0 && W + xs < 0 && 1 < H;
 	const cb_u2 fx0 = __builtin_amdgcn_raw_buffer_load_b64(rv, edge0 ? 0u : OOB, 0, 0);
 	const cb_u2 fx1 = __builtin_amdgcn_raw_buffer_load_b64(rv, edge1 ? (cb_u32)W * 4u : OOB, 0, 0);
-	// the entries' positions; the runs of the small-class ones (at most four rows of at most four values: nearly all of a texture's
+	// the entries' places; the runs of the small-class ones (at most four rows of at most four values: nearly all of a texture's
 	// entries) are requested now, behind the rows: lines this wave and its neighbours are fetching anyway
-	const bool ehas = (cb_u32)lane < nent;
-	const cb_u32 erem = ent.x - (cb_u32)d * (cb_u32)HWi;   // y * W + x
-	const int ey = (int)(erem / (cb_u32)W), ex = (int)erem - ey * W;
-	const int ery = ey - (y0 - 1), ecx = ex - xb;
-	const bool e1 = ehas && erem < (cb_u32)HWi && (unsigned)ery < (unsigned)(R + 2) && (unsigned)ecx < 256u;   // a first-pass entry of this tile
-	const bool e2 = e1 && ey >= y0 && ey < y1 && (unsigned)(ecx - 2) < 252u;                                   // ... also one of the wave's own outputs
-	const bool esmall = e1 && (ent.y & 0xf0u) == 0xe0u;
+	const L2xEntry E = l2x_entry<R>(ent, (cb_u32)lane < nent, y0, y1, xb, W);
+	const bool esmall = E.first && (ent.y & 0xf0u) == 0xe0u;
 	cb_u4 ev[4];
 	int enn[4];
-	small_request(A, rv, esmall, ent, erem, ev, enn);
+	small_request(A, rv, esmall, ent, E.rem, ev, enn);
 	if (edge0) { v[2].z = fx0.x; v[2].w = fx0.y; }
 	if (edge1) { v[3].z = fx1.x; v[3].w = fx1.y; }
 	const bool allin = __all(inr == 15u);
@@ -745,21 +853,27 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 		}
 	}
 	// ... its listed outputs, out of the input plane
-	if (e1) T[ery * 256 + ecx] = esmall ? small_sum(ev, enn) : list_entry_value(A, rv, d, ent, erem);
+	if (E.first) T[E.ry * 256 + E.cx] = esmall ? small_sum(ev, enn) : list_entry_value(A, rv, d, ent, E.rem);
 	for (cb_u32 i = 64u + (cb_u32)lane; i < nent; i += 64) {
 		const cb_u4 e = *(const cb_u4 *)l2x_slot(rr, i);
-		const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;
-		if (rem >= (cb_u32)HWi) continue;
-		const int y = (int)(rem / (cb_u32)W), x = (int)rem - y * W;
-		const int ry = y - (y0 - 1), cx = x - xb;
-		if ((unsigned)ry >= (unsigned)(R + 2) || (unsigned)cx >= 256u) continue;
-		T[ry * 256 + cx] = list_entry_value(A, rv, d, e, rem);
+		const L2xEntry F = l2x_entry<R>(e, true, y0, y1, xb, W);
+		if (F.first) T[F.ry * 256 + F.cx] = list_entry_value(A, rv, d, e, F.rem);
 	}
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-	// second pass: the wave's R rows out of the tile
+	// second pass.  Its listed outputs first, over the first pass's values in the tile -- up to 64 entries (one per lane: nearly every
+	// wave of a texture): their values replace the rows' in the tile, whose first-pass values nobody needs any more by then, and the rows
+	// are stored from there.  More entries: the rows are stored first and the entries' values behind them, once those stores have
+	// completed (the same addresses, written by other lanes).
+	const bool through_tile = nent <= 64u;
+	float val2 = 0;
+	if (through_tile && nent) {
+		const bool own_small = E.own && esmall;
+		if (__any(own_small)) val2 = second_pass_small<R>(A, rv, rp0, rp1, T, sh, own_small, ent, E.y, E.x, y0, xb);
+		if (E.own && !esmall) val2 = second_pass_entry<R>(A, rv, T, d, ent, E.rem, E.y, E.x, y0, xb);
+	}
 	cb_f4 res[R];
 	{
 		cb_f4 m[R + 2];
@@ -774,18 +888,12 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 			__builtin_amdgcn_sched_barrier(0);
 		}
 	}
-	// ... its listed outputs, over the first pass's values.  Up to 64 entries (one per lane, nearly every wave of a texture): their values
-	// replace the rows' in the tile -- whose first-pass values nobody needs any more -- and the rows are stored from there; more: the rows
-	// are stored first and the entries' values behind them, once those stores have completed (the same addresses, written by other lanes)
-	const bool through_tile = nent <= 64u;
 	if (through_tile && nent) {
-		float val2 = 0;
-		if (e2) val2 = second_pass_entry<R>(A, rv, T, d, ent, erem, ey, ex, y0, xb);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();   // (every lane's reads of first-pass values are done)
 #pragma unroll
 		for (int k = 0; k < R; ++k) *(cb_f4 *)(T + k * 256 + 4 * lane) = res[k];
-		if (e2) T[(ey - y0) * 256 + ecx] = val2;
+		if (E.own) T[(E.y - y0) * 256 + E.cx] = val2;
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -808,11 +916,8 @@ __global__ void __launch_bounds__(256) cbca_lean2x_kernel(const LeanArgs A)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		for (cb_u32 i = (cb_u32)lane; i < nent; i += 64) {
 			const cb_u4 e = *(const cb_u4 *)l2x_slot(rr, i);
-			const cb_u32 rem = e.x - (cb_u32)d * (cb_u32)HWi;
-			if (rem >= (cb_u32)HWi) continue;
-			const int y = (int)(rem / (cb_u32)W), x = (int)rem - y * W;
-			if (y < y0 || y >= y1 || (unsigned)(x - xb - 2) >= 252u) continue;   // (the wave's own outputs only)
-			A.vout[(size_t)d * HWi + rem] = second_pass_entry<R>(A, rv, T, d, e, rem, y, x, y0, xb);
+			const L2xEntry F = l2x_entry<R>(e, true, y0, y1, xb, W);
+			if (F.own) A.vout[(size_t)d * HWi + F.rem] = second_pass_entry<R>(A, rv, T, d, e, F.rem, F.y, F.x, y0, xb);
 		}
 	}
 }
@@ -895,7 +1000,8 @@ __global__ void __launch_bounds__(256) cbca_classify2x_kernel(const LeanArgs A)
 			cost += outside * taps;
 			if (!fits) { ew[0] = 0xffu; ew[1] = ew[2] = 0u; }
 			else ew[0] |= small ? (0xe0u | (cb_u32)u | ((cb_u32)dn << 2)) : (cb_u32)(u | (dn << 4));
-			if (written + (cb_u32)i < rr.cap) *(cb_u4 *)l2x_slot(rr, written + (cb_u32)i) = cb_u4{idx, ew[0], ew[1], ew[2]};
+			// (word 0: the output's place in the wave's tile -- first-pass row | column << 8 -- instead of its voxel index: no division in the passes)
+			if (written + (cb_u32)i < rr.cap) *(cb_u4 *)l2x_slot(rr, written + (cb_u32)i) = cb_u4{(cb_u32)(ye - (y0 - 1)) | ((cb_u32)(xe - xb) << 8), ew[0], ew[1], ew[2]};
 		}
 		written += (cb_u32)cnt;
 		cnt = 0;
@@ -976,6 +1082,7 @@ static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, con
 	A.hdr = (uint32_t *)plan;
 	A.D = D; A.H = H; A.W = W; A.direction = direction;
 	A.pitch = two_pass ? 252 : 256; A.xoff = two_pass ? -2 : 0;
+	A.wpb = 4;
 	A.gx = (int)cdiv(W, A.pitch);
 	A.rb = two_pass ? lean2x_rows(rb) : lean_rows(rb);
 	A.rbcode = (cb_u32)A.rb | (two_pass ? 0x100u : 0u);
@@ -1010,7 +1117,7 @@ int cbca_lean_rows(int D, int H, int W, int rb, bool two_pass)
 // blocks of 4 waves: x over one plane's (chunk, strip) pairs -- order 1: eight bands of gyb chunks, band = blockIdx.x & 7 --, y = plane
 static dim3 lean_grid(const LeanArgs &A)
 {
-	const unsigned per_plane = A.order == 1 ? 8u * cdiv((int64_t)A.gx * A.gyb, 4) : cdiv((int64_t)A.gx * A.gy, 4);
+	const unsigned per_plane = A.order == 1 ? 8u * cdiv((int64_t)A.gx * A.gyb, A.wpb) : cdiv((int64_t)A.gx * A.gy, A.wpb);
 	return dim3(per_plane, (unsigned)A.D);
 }
 
@@ -1087,11 +1194,12 @@ int cbca_lean(const void *packed, const void *plan, size_t plan_bytes, const flo
 int cbca_lean2x(const void *packed, const void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
                 int route, hipStream_t st, const CbcaCfg &cfg)
 {
-	const LeanArgs A = lean_args(packed, (void *)plan, plan_bytes, vin, vout, D, H, W, direction, route, cfg.lean_rb, cfg.nd, 0, true);
+	LeanArgs A = lean_args(packed, (void *)plan, plan_bytes, vin, vout, D, H, W, direction, route, cfg.lean_rb, cfg.nd, 0, true);
+	A.wpb = L2X_WPB;
 	const dim3 blocks = lean_grid(A);
-	if (A.rb == 4) hipLaunchKernelGGL(cbca_lean2x_kernel<4>, blocks, dim3(256), 0, st, A);
-	else if (A.rb == 12) hipLaunchKernelGGL(cbca_lean2x_kernel<12>, blocks, dim3(256), 0, st, A);
-	else hipLaunchKernelGGL(cbca_lean2x_kernel<8>, blocks, dim3(256), 0, st, A);
+	if (A.rb == 4) hipLaunchKernelGGL((cbca_lean2x_kernel<4, L2X_WPB>), blocks, dim3(64 * L2X_WPB), 0, st, A);
+	else if (A.rb == 12) hipLaunchKernelGGL((cbca_lean2x_kernel<12, L2X_WPB>), blocks, dim3(64 * L2X_WPB), 0, st, A);
+	else hipLaunchKernelGGL((cbca_lean2x_kernel<8, L2X_WPB>), blocks, dim3(64 * L2X_WPB), 0, st, A);
 	return check_launch("cbca_lean2x");
 }
 
