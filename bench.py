@@ -55,7 +55,7 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 KERNEL_NAMES = {
     "join": "join_owner_kernel (StereoJoin on v_mfma_f32_32x32x2_f32, both volumes, NaN fill + fix_border folded in)",
-    "cbca": "cbca_tile_kernel on real-scene arm statistics, cbca_lean_kernel on textures, cbca_strip_kernel for arms > 13 (the pair's route word picks on the device; one iteration over one volume per launch)",
+    "cbca": "cbca_tile_kernel on real-scene arm statistics (one iteration over one volume per launch), cbca_lean2x_kernel on textures (two iterations per launch), cbca_strip_kernel for arms > 13 (the pair's route word picks on the device)",
     "sgm": "sgm_pass_kernel (right+left sweep, down sweep, up sweep: 3 launches over both volumes)",
 }
 
@@ -72,8 +72,14 @@ def algorithmic_bytes(preset, H, W, D, C):
     return b
 
 
-def launches_per_step(preset, C):
-    return {"join": 1 if C else 0, "cbca": 2 * (preset["cbca_i1"] + preset["cbca_i2"]), "sgm": 3 * preset["sgm_i"]}
+def launches_per_step(preset, C, pair=None):
+    """launches of the dominant kernel of each group per pair.  cbca: one per iteration and volume -- on the texture route
+    (cbca_lean2x_kernel, 4 < L1 - 1 <= 13) one per PAIR of iterations and volume, an odd last iteration on its own."""
+    i1, i2 = preset["cbca_i1"], preset["cbca_i2"]
+    cb = 2 * (i1 + i2)
+    if pair == "texture" and 4 < preset["L1"] - 1 <= 13:
+        cb = 2 * ((i1 + 1) // 2 + (i2 + 1) // 2)
+    return {"join": 1 if C else 0, "cbca": cb, "sgm": 3 * preset["sgm_i"]}
 
 
 def pick_dominant(stage_ms, ab):
@@ -308,7 +314,7 @@ def cbca_additions(xb, prm, D, n_planes=8):
 
 def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None, xb=None, pair=None):
     ab = algorithmic_bytes(prm, H, W, D, max(C, 0))
-    nl = launches_per_step(prm, max(C, 0))
+    nl = launches_per_step(prm, max(C, 0), pair)
     traffic_all = {}
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % cfg_key)
     if os.path.exists(tfile):
@@ -329,14 +335,18 @@ def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None, xb=
         if prm["L1"] <= 5:
             kname = "cbca_tile_kernel<4, ...>"
         elif pair == "texture":
-            kname = "cbca_lean_kernel<8, ...> (texture route: 3 x 3 means of the whole plane + the listed larger supports; cbca_classify once per pair and direction)"
+            kname = ("cbca_lean2x_kernel<8, 1> (texture route: TWO iterations over one volume per launch -- the first one's rows stay in LDS --, 3 x 3 means of the "
+                     "whole plane + the listed larger supports of both; cbca_classify2x once per pair and direction)")
         elif pair is not None:
             kname = "cbca_tile_kernel<13, ...> (real-scene arm statistics)"
         else:
-            kname = "cbca_tile_kernel<13, ...> (real-scene arm statistics) or cbca_lean_kernel (texture), by the pair's route word"
-        kname += " (one iteration over one volume per launch)"
+            kname = "cbca_tile_kernel<13, ...> (real-scene arm statistics) or cbca_lean2x_kernel (texture), by the pair's route word"
+        if pair != "texture" or prm["L1"] <= 5:
+            kname += " (one iteration over one volume per launch)"
     rec = dict(bound="hbm", kernel=kname, picked_by="largest measured stage time", achieved=round(achieved, 1),
-               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic_all.get(dom),
+               peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+               # (profiles/traffic_*.json holds cbca's bytes per ITERATION; per launch like `achieved`: x the iterations a launch runs)
+               traffic=(round(traffic_all[dom] * (2 * (prm["cbca_i1"] + prm["cbca_i2"]) / nl[dom])) if dom == "cbca" and traffic_all.get(dom) else traffic_all.get(dom)),
                launches_per_step=nl[dom], algorithmic_bytes_per_launch=round(ab[dom] / nl[dom]),
                avg_launch_ms=round(acc[dom] / nl[dom], 4), kernels=kernels,
                pipeline_frac=round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
@@ -396,7 +406,8 @@ def sub_record(device, config, reps=10, pair=None):
     rec = dict(workload=name, pair=PAIR_NOTE[pair], ms_per_pair=round(float(np.median(times)), 4), ms_per_pair_min=round(min(times), 4),
                value_MPix_disp_s=round(2.0 * H * W * D / 1e6 / (float(np.median(times)) * 1e-3), 1),
                stage_ms={k: round(v, 4) for k, v in acc.items()},
-               cbca_ms_per_launch=round(acc.get("cbca", 0) / max(1, 2 * n_it), 4),
+               cbca_ms_per_launch=round(acc.get("cbca", 0) / max(1, launches_per_step(prm, max(C, 0), pair)["cbca"]), 4),
+               cbca_ms_per_iteration=round(acc.get("cbca", 0) / max(1, 2 * n_it), 4),
                roofline=roofline_record(config, prm, H, W, D, C, acc, float(np.median(times)), None, xb, pair),
                verify=verify_against_reference(cfg, xb, kw, prm, D, ws, config))
     del ws, xb, kw

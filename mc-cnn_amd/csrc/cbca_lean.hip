@@ -770,7 +770,7 @@ __device__ __forceinline__ float second_pass_small(const LeanArgs &A, const __am
 }
 
 #ifndef MC_LEAN2X_WPB
-#define MC_LEAN2X_WPB 2
+#define MC_LEAN2X_WPB 1
 #endif
 constexpr int L2X_WPB = MC_LEAN2X_WPB;   // waves per block: 10 KB of LDS per wave (R = 8); blocks of two waves fill a CU's 160 KB in finer steps than blocks of four
 

@@ -21,7 +21,7 @@ def main(d, config):
     out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean over dispatches; source: " + d}
     # cbca: one ITERATION over one volume = the launches of cbca_by_arms (tile instances + strip kernel, all but one of which
     # stand down at their first instruction): summed, not averaged
-    groups = {"sgm": ("sgm_pass_kernel",), "cbca": ("cbca_strip_kernel", "cbca_tile_kernel", "cbca_lean_kernel", "cbca_classify_kernel", "cbca_list_kernel"),
+    groups = {"sgm": ("sgm_pass_kernel",), "cbca": ("cbca_strip_kernel", "cbca_tile_kernel", "cbca_lean_kernel", "cbca_lean2x_kernel", "cbca_classify_kernel", "cbca_classify2x_kernel", "cbca_list_kernel", "cbca_list_cost_kernel"),
               "join": ("join_owner_kernel",),
               "transpose": ("transpose_kernel", "transpose4_kernel")}
     for g, pat in groups.items():
@@ -37,7 +37,8 @@ def main(d, config):
         if g == "cbca":
             # bytes of ALL dispatches of the group / iterations; an iteration launches one kernel of each family (strip, tile<4, tile<13:
             # the plan-writing and plan-reading instances of a tile family are different kernels of the same family)
-            # (textured pairs: the lean kernel per iteration -- the listed outputs inside it -- and cbca_classify_kernel once per direction)
+            # (textured pairs: cbca_lean2x_kernel per PAIR of iterations -- the strip kernel's stand-down launches still count the iterations --
+            # and cbca_classify2x_kernel once per direction)
             fam = lambda k: ("strip" if "cbca_strip" in k else "lean" if "cbca_lean" in k else "once" if ("cbca_classify" in k or "cbca_list" in k) else
                              "tile4" if "cbca_tile_kernel<4," in k else "tile13")
             allb = sum((2 * sum(acc[k]["FETCH_SIZE"]) + sum(acc[k]["WRITE_SIZE"])) * 1024 for k in ks)
