@@ -25,7 +25,7 @@ bash scripts/gpu_pmc.sh $TAG kitti_fast 3 > /dev/null
 bash scripts/gpu_pmc.sh $TAG kitti_slow 2 > /dev/null
 bash scripts/gpu_pmc.sh $TAG mb_slow 1 > /dev/null
 bash scripts/gpu_pmc.sh $TAG mb_slow 1 natural > /dev/null
-timeout 100 scripts/microbench/valu_rate.bin > $O/valu_rate.txt 2>&1
-timeout 120 scripts/microbench/bw_sizes.bin > $O/bw_sizes.txt 2>&1
-timeout 120 scripts/microbench/bw_lean.bin > $O/bw_lean.txt 2>&1
+[ -x scripts/microbench/valu_rate.bin ] && timeout 100 scripts/microbench/valu_rate.bin > $O/valu_rate.txt 2>&1
+[ -x scripts/microbench/bw_sizes.bin ] && timeout 120 scripts/microbench/bw_sizes.bin > $O/bw_sizes.txt 2>&1
+[ -x scripts/microbench/bw_lean.bin ] && timeout 120 scripts/microbench/bw_lean.bin > $O/bw_lean.txt 2>&1
 ls $O
