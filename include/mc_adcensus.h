@@ -228,8 +228,9 @@ enum { MC_SKIP_NONE = 0, MC_SKIP_CBCA = 1, MC_SKIP_SGM = 2, MC_SKIP_OCCLUSION = 
        MC_SKIP_MEDIAN = 5, MC_SKIP_BILATERAL = 6 };
 
 /* Workspace bytes mc_predict needs for the given problem: six volumes, six maps, the SGM edge classes, arms and packed
- * arm lengths; for parameter sets that aggregate at least twice with L1 <= 14 also the tile kernel's plan (mc_cbca_plan_bytes,
- * ~3.6 bytes per voxel) per computed direction. */
+ * arm lengths; for parameter sets that aggregate at least twice with L1 <= 14 also the plan area of the aggregation kernels
+ * (mc_cbca_plan_bytes, ~3.6 bytes per voxel: the tile kernel's item order or, on textured pairs, the per-wave records of the
+ * two-passes-per-launch kernel) per computed direction. */
 size_t mc_predict_workspace_bytes(const mc_params *p, int C, int D, int H, int W);
 
 /* stereo_predict(x_batch, id), main.lua:929-1082, from the cost-volume stage on.
@@ -298,7 +299,13 @@ int mc_write_pfm(const float *img, int height, int width, const char *fname);
  * kernel takes over if the list is another problem's or did not fit.  There `rb` = rows per wave (2 / 4 / 8, else the product's),
  * `d0` = launch variant (bit 2 the listed outputs in a launch of their own, bit 4 one band of rows per XCD, bits 5 / 6
  * non-temporal loads / stores), `nd` = slots the list may hold (0 = all of its room).
- * Lets small-shape parity tests reach what the benchmarked sizes and parameter sets select. */
+ * 10 / 11 = TWO aggregation passes in one launch (cbca_lean2x_kernel: what mc_predict runs pairs of passes in on textured pairs);
+ * vol_out = the volume after the second pass.  10 first writes the per-wave records of the listed outputs behind the packed lengths,
+ * 11 reads them; the strip kernel takes both passes if the records are another problem's, a wave's entries do not fit its record or
+ * the pair is not a texture (cost limit).  `scratch` additionally holds 512 bytes + one volume (the strip kernel's middle volume)
+ * behind the plan area; `rb` = rows per wave (4 / 8 / 12, else the product's), `d0` > 0 = the cost limit in recomputed values per voxel.
+ * Lets small-shape parity tests reach what the benchmarked sizes and parameter sets select.
+ * mc_cbca_plan_bytes: the larger of the tile kernel's plan and the two-pass records (4 KB per wave of 8 rows x 252 columns). */
 size_t mc_cbca_plan_bytes(int D, int H, int W);
 int mc_cbca_ws_cfg(const float *x0c, const float *x1c, const float *vol_in, float *vol_out,
                    int D, int H, int W, int direction, void *scratch, size_t scratch_bytes,
