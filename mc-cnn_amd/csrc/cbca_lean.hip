@@ -1070,7 +1070,7 @@ static int lean_rows(int rb) { return (rb == 2 || rb == 4 || rb == 8) ? rb : MC_
 #ifndef MC_LEAN2X_RB_DEFAULT
 #define MC_LEAN2X_RB_DEFAULT 8
 #endif
-static int lean2x_rows(int rb) { return (rb == 4 || rb == 8 || rb == 12) ? rb : MC_LEAN2X_RB_DEFAULT; }
+static int lean2x_rows(int rb) { return (rb == 4 || rb == 6 || rb == 8 || rb == 10 || rb == 12) ? rb : MC_LEAN2X_RB_DEFAULT; }
 
 static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,
                           int route, int rb, int cap_limit = 0, int order = 0, bool two_pass = false)
@@ -1198,6 +1198,8 @@ int cbca_lean2x(const void *packed, const void *plan, size_t plan_bytes, const f
 	A.wpb = L2X_WPB;
 	const dim3 blocks = lean_grid(A);
 	if (A.rb == 4) hipLaunchKernelGGL((cbca_lean2x_kernel<4, L2X_WPB>), blocks, dim3(64 * L2X_WPB), 0, st, A);
+	else if (A.rb == 6) hipLaunchKernelGGL((cbca_lean2x_kernel<6, L2X_WPB>), blocks, dim3(64 * L2X_WPB), 0, st, A);
+	else if (A.rb == 10) hipLaunchKernelGGL((cbca_lean2x_kernel<10, L2X_WPB>), blocks, dim3(64 * L2X_WPB), 0, st, A);
 	else if (A.rb == 12) hipLaunchKernelGGL((cbca_lean2x_kernel<12, L2X_WPB>), blocks, dim3(64 * L2X_WPB), 0, st, A);
 	else hipLaunchKernelGGL((cbca_lean2x_kernel<8, L2X_WPB>), blocks, dim3(64 * L2X_WPB), 0, st, A);
 	return check_launch("cbca_lean2x");

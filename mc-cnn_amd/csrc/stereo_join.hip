@@ -256,9 +256,7 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 			fgo[t][pass] = px < W ? (unsigned)(px * ds) * 4u : OOBF;
 		}
 	}
-	auto do_tile = [&](int t, int J, const float (&part)[KSTEPS], int p0) {
-		float *__restrict__ ring = rings + t * (32 * 64);
-		floatx16 acc;
+	auto tile_product = [&](int t, const float (&part)[KSTEPS], int p0, floatx16 &acc) {
 #pragma unroll
 		for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 		// partner tile entirely outside the image: nothing to multiply, the whole tile is NaN
@@ -269,6 +267,9 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 				acc = SIDE == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(own[t][kk], part[kk], acc, 0, 0, 0)
 				                : __builtin_amdgcn_mfma_f32_32x32x2f32(part[kk], own[t][kk], acc, 0, 0, 0);
 		}
+	};
+	auto tile_store = [&](int t, int J, int p0, const floatx16 &acc) {
+		float *__restrict__ ring = rings + t * (32 * 64);
 		const int jbit = (J & 1) << 5;
 		// interior tile: every d of it lies in [0, D) and every partner pixel inside the image
 		const bool interior = J >= 1 && 32 * J + 31 < D && (SIDE == 0 ? p0 >= 0 : p0 + 31 < W);
@@ -305,12 +306,54 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 			}
 		}
 	};
+	// MC_JOIN_ORDER 0: product and stores of one own tile after the other; 1: the products of a step's own tiles first (the chains of
+	// dependent MFMAs of different tiles are independent of each other), then their stores
+#ifndef MC_JOIN_ORDER
+#define MC_JOIN_ORDER 0
+#endif
 	auto do_step = [&](int s, const float (&part)[KSTEPS]) {
 		const int T = partner_of(s);
+		floatx16 acc[NT];
+		if (MC_JOIN_ORDER == 2 && NT == 2) {   // both own tiles active and the partner tile inside the image: the two chains interleaved, MFMA by MFMA
+			const int J0 = SIDE == 0 ? tile0 - T : T - tile0, J1 = SIDE == 0 ? J0 + 1 : J0 - 1;
+			const int p0 = 32 * T;
+			const bool both = J0 >= 0 && J0 < nJ && J1 >= 0 && J1 < nJ && (SIDE == 0 ? (p0 + 31 >= 0) : (p0 < W));
+			if (both) {
 #pragma unroll
-		for (int t = 0; t < NT; ++t) {
-			const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
-			if (J >= 0 && J < nJ) do_tile(t, J, part, 32 * T);
+				for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+#pragma unroll
+				for (int kk = 0; kk < KSTEPS; ++kk) {
+					acc[0] = SIDE == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(own[0][kk], part[kk], acc[0], 0, 0, 0)
+					                   : __builtin_amdgcn_mfma_f32_32x32x2f32(part[kk], own[0][kk], acc[0], 0, 0, 0);
+					acc[1] = SIDE == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(own[1][kk], part[kk], acc[1], 0, 0, 0)
+					                   : __builtin_amdgcn_mfma_f32_32x32x2f32(part[kk], own[1][kk], acc[1], 0, 0, 0);
+				}
+				tile_store(0, J0, p0, acc[0]);
+				tile_store(1, J1, p0, acc[1]);
+			} else {
+#pragma unroll
+				for (int t = 0; t < NT; ++t) {
+					const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
+					if (J >= 0 && J < nJ) { tile_product(t, part, p0, acc[0]); tile_store(t, J, p0, acc[0]); }
+				}
+			}
+		} else if (MC_JOIN_ORDER == 1) {
+#pragma unroll
+			for (int t = 0; t < NT; ++t) {
+				const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
+				if (J >= 0 && J < nJ) tile_product(t, part, 32 * T, acc[t]);
+			}
+#pragma unroll
+			for (int t = 0; t < NT; ++t) {
+				const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
+				if (J >= 0 && J < nJ) tile_store(t, J, 32 * T, acc[t]);
+			}
+		} else {
+#pragma unroll
+			for (int t = 0; t < NT; ++t) {
+				const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
+				if (J >= 0 && J < nJ) { tile_product(t, part, 32 * T, acc[0]); tile_store(t, J, 32 * T, acc[0]); }
+			}
 		}
 	};
 	// The prefetch of the next partner tile is issued UNCONDITIONALLY (past the last step it fetches a tile that is never
