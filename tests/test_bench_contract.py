@@ -116,3 +116,28 @@ def test_multi_gpu_default_is_configs4_with_per_rank_pairs():
     assert json.loads(one.stdout.strip().splitlines()[-1])["config"] == "tiny"
     d = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=600)
     assert json.loads(d.stdout.strip().splitlines()[-1])["config"] == "kitti_fast"   # one GPU: BASELINE configs[1]
+
+
+def test_texture_route_launches_run_two_iterations_each():
+    bench = _bench()
+    """cbca_lean2x_kernel runs the iterations of a textured pair two per launch (an odd last one on its own): the roofline record's
+    launches, algorithmic bytes per launch and traffic per launch follow; the other routes keep one iteration per launch"""
+    import mc_cnn_amd as mc
+    mb = dict(mc.PRESETS["mb_slow"])
+    assert (mb["cbca_i1"], mb["cbca_i2"]) == (2, 16)
+    assert bench.launches_per_step(mb, 0, "texture")["cbca"] == 2 * (1 + 8)
+    assert bench.launches_per_step(mb, 0, "natural")["cbca"] == 2 * 18 == bench.launches_per_step(mb, 0)["cbca"]
+    odd = dict(mb, cbca_i1=1, cbca_i2=5)
+    assert bench.launches_per_step(odd, 0, "texture")["cbca"] == 2 * (1 + 3)
+    kitti = dict(mc.PRESETS["kitti_slow"])                       # L1 = 5: arms <= 4, the tile kernel's short-arm instance whatever the pair
+    assert bench.launches_per_step(kitti, 0, "texture")["cbca"] == 2 * (kitti["cbca_i1"] + kitti["cbca_i2"])
+    H, W, D = 1000, 1500, 256
+    acc = {"cbca": 16.0, "sgm": 6.4}
+    rec = bench.roofline_record("mb_slow", mb, H, W, D, 0, acc, 25.0, None, None, "texture")
+    assert rec["launches_per_step"] == 18 and rec["algorithmic_bytes_per_launch"] == 4 * 4 * D * H * W
+    assert "cbca_lean2x_kernel" in rec["kernel"] and "one iteration over one volume per launch" not in rec["kernel"]
+    tfile = os.path.join(ROOT, "profiles", "traffic_mb_slow.json")
+    if os.path.exists(tfile):                                     # profiles/traffic_*.json: cbca's bytes per ITERATION
+        per_it = json.load(open(tfile))["cbca"]
+        assert rec["traffic"] == round(per_it * 2)
+        assert rec["traffic"] < rec["algorithmic_bytes_per_launch"]   # the point of the kernel: fewer bytes moved than the count
