@@ -14,6 +14,10 @@
 // Outputs without a partner are copied through by the lean kernel (adcensus.cu:353-354).  The strip kernel (cbca.hip), which
 // does all of this per pass, remains what adcensus.cbca runs on its own (no state between calls) and the fallback when the
 // list does not fit.
+//
+// Second half of the file: cbca_lean2x_kernel runs TWO consecutive passes per launch (the first one's rows stay in LDS) out of
+// per-wave RECORDS that cbca_classify2x_kernel writes -- what mc_predict runs on such pairs; the single-pass kernels above are
+// what the passes were in the first half of round 4 and stay behind the test hook (mc_cbca_ws_cfg forms 8 / 9).
 #include "cbca_common.h"
 #include <algorithm>
 
