@@ -37,7 +37,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 
-#define MC_ABI_VERSION 7
+#define MC_ABI_VERSION 8
 #define MC_EINVAL (-22)
 #define MC_SGM_MAX_D 512   /* reference: __shared__ float[400], adcensus.cu:574 */
 #define MC_JOIN_MAX_C 128  /* reference: float L_cache[128], adcensus.cu:1460-1461 */
@@ -283,6 +283,12 @@ int mc_write_png16(const float *img, int height, int width, const char *fname);
 
 /* adcensus.writePFM(img, fname), adcensus.cu:1706-1721: "Pf", "width height", scale -0.003922, rows as stored, raw floats. */
 int mc_write_pfm(const float *img, int height, int width, const char *fname);
+
+/* adcensus.grey2jet(grey_img, col_img), adcensus.cu:2000-2053 ("CPU implementation": torch.DoubleTensor arguments; the debug images of
+ * main.lua:503,1242,1260): val = 4 * grey[y][x] through the five linear pieces of the jet colour map into col[(c * height + y) * width + x],
+ * c = 0 (red), 1, 2, in doubles.  Where the reference prints the value and asserts (val outside [-0.1, 4.1], NaN) this returns MC_EINVAL
+ * with the pixel in mc_last_error; pixels before it are written, as in the reference. */
+int mc_grey2jet(const double *grey, double *col, int height, int width);
 
 /* ---- test / bench hooks (not part of the reference's surface) ---------------- */
 

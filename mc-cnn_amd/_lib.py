@@ -17,7 +17,7 @@ SYMBOLS = [
     "mc_interpolate_mismatch", "mc_subpixel_enchancement", "mc_median2d", "mc_mean2d", "mc_gaussian_host",
     "mc_normalize_forward", "mc_predict_workspace_bytes", "mc_predict", "mc_predict_timed",
     "mc_cbca_plan_bytes", "mc_cbca_ws_cfg", "mc_transpose_cfg",
-    "mc_read_png16", "mc_write_png16", "mc_write_pfm", "mc_sgm2_contract_violations",
+    "mc_read_png16", "mc_write_png16", "mc_write_pfm", "mc_grey2jet", "mc_sgm2_contract_violations",
 ]
 
 
@@ -79,6 +79,7 @@ def _load():
         "mc_read_png16": [C.c_char_p, vp, i64, C.POINTER(i), C.POINTER(i)],
         "mc_write_png16": [vp, i, i, C.c_char_p],
         "mc_write_pfm": [vp, i, i, C.c_char_p],
+        "mc_grey2jet": [vp, vp, i, i],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -86,7 +87,7 @@ def _load():
         if name not in ("mc_sgm2_tmp_bytes", "mc_cbca_scratch_bytes", "mc_cbca_plan_bytes", "mc_census_scratch_bytes",
                         "mc_fc_stack_workspace_bytes", "mc_conv3x3_workspace_bytes"):
             fn.restype = C.c_int
-    if lib.mc_version() != 7:
+    if lib.mc_version() != 8:
         raise ImportError("mc-cnn_amd: ABI version mismatch")
     return lib
 

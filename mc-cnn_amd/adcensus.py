@@ -344,3 +344,15 @@ def writePFM(img, fname):
     import ctypes as C
     assert img.dtype == torch.float32 and img.device.type == "cpu" and img.is_contiguous() and img.dim() == 2
     check(lib.mc_write_pfm(C.c_void_p(img.data_ptr()), img.shape[0], img.shape[1], str(fname).encode()), "writePFM")
+
+
+def grey2jet(grey_img, col_img):
+    """adcensus.grey2jet(grey_img, col_img) -- adcensus.cu:2000-2053 (host code there too; the debug images of main.lua:503,1242,1260):
+    (H,W) float64 CPU tensor with values in [-0.025, 1.025] -> (..., 3, H, W) float64 CPU tensor, the jet colour map."""
+    import ctypes as C
+    assert grey_img.dtype == torch.float64 and grey_img.device.type == "cpu" and grey_img.is_contiguous() and grey_img.dim() == 2, \
+        "grey2jet: contiguous (H,W) float64 CPU tensor expected"
+    assert col_img.dtype == torch.float64 and col_img.device.type == "cpu" and col_img.is_contiguous()
+    if 3 * grey_img.numel() != col_img.numel():
+        raise ValueError("Size mismatch")   # (the reference's luaL_error, adcensus.cu:2008)
+    check(lib.mc_grey2jet(C.c_void_p(grey_img.data_ptr()), C.c_void_p(col_img.data_ptr()), grey_img.shape[0], grey_img.shape[1]), "grey2jet")

@@ -1,5 +1,6 @@
 // Host side of libadcensus that `main.lua` reaches through the same table: adcensus.readPNG16 / writePNG16 / writePFM
-// (adcensus.cu:1670-1721; callers main.lua:1212,1218 and the KITTI / Middlebury submission paths).  Plain host code on HOST
+// (adcensus.cu:1670-1721; callers main.lua:1212,1218 and the KITTI / Middlebury submission paths) and adcensus.grey2jet
+// (adcensus.cu:2000-2053; the debug images of main.lua:503,1242,1260).  Plain host code on HOST
 // pointers (the reference takes torch.FloatTensor here, not CudaTensor); no device, no stream.
 //
 // The reference goes through png++ / libpng; neither has headers in this image, zlib has: the 16-bit greyscale PNG codec
@@ -173,6 +174,42 @@ int mc_write_pfm(const float *img, int height, int width, const char *fname)
 	if (fprintf(fp.f, "Pf\n%d %d\n-0.003922\n", width, height) < 0 || fwrite(img, 4, (size_t)height * width, fp.f) != (size_t)height * width) {
 		set_error("mc_write_pfm: write to %s failed", fname);
 		return MC_EINVAL;
+	}
+	return 0;
+}
+
+// adcensus.grey2jet(grey_img, col_img), adcensus.cu:2000-2053: the jet colour map in five linear pieces of val = 4 * grey, doubles,
+// planes red / green / blue.  The reference asserts on a value outside [-0.1, 4.1]; here: an error with the pixel named.
+int mc_grey2jet(const double *grey, double *col, int height, int width)
+{
+	if (!grey || !col || height < 1 || width < 1) { set_error("mc_grey2jet: bad argument"); return MC_EINVAL; }
+	const size_t hw = (size_t)height * width;
+	for (int i = 0; i < height; i++) {
+		for (int j = 0; j < width; j++) {
+			const double val = grey[(size_t)i * width + j] * 4;
+			double r = 0, g = 0, b = 0;
+			if (-0.1 <= val && val < 0.5) {
+				b = 0.5 + val;
+			} else if (0.5 <= val && val < 1.5) {
+				g = val - 0.5;
+				b = 1;
+			} else if (1.5 <= val && val < 2.5) {
+				r = val - 1.5;
+				g = 1;
+				b = 1 - (val - 1.5);
+			} else if (2.5 <= val && val < 3.5) {
+				r = 1;
+				g = 1 - (val - 2.5);
+			} else if (3.5 <= val && val <= 4.1) {
+				r = 1 - (val - 3.5);
+			} else {
+				set_error("mc_grey2jet: val = %f at (%d, %d) is outside the colour map's range [-0.1, 4.1]", val, i, j);
+				return MC_EINVAL;
+			}
+			col[(size_t)i * width + j] = r;
+			col[hw + (size_t)i * width + j] = g;
+			col[2 * hw + (size_t)i * width + j] = b;
+		}
 	}
 	return 0;
 }

@@ -83,10 +83,11 @@ int mc_predict(const mc_params *p, const float *x0, const float *x1,
 int mc_read_png16(const char *fname, float *img, int64_t capacity, int *height, int *width);
 int mc_write_png16(const float *img, int height, int width, const char *fname);
 int mc_write_pfm(const float *img, int height, int width, const char *fname);
+int mc_grey2jet(const double *grey, double *col, int height, int width);
 ]]
 
 local lib = ffi.load('mcadcensus')
-local MC_ABI_VERSION = 7   -- include/mc_adcensus.h; tests/test_lua_shim.py checks this constant and every prototype above
+local MC_ABI_VERSION = 8   -- include/mc_adcensus.h; tests/test_lua_shim.py checks this constant and every prototype above
 assert(lib.mc_version() == MC_ABI_VERSION, ('libmcadcensus ABI version %d, this shim is written for %d'):format(
    lib.mc_version(), MC_ABI_VERSION))
 
@@ -256,6 +257,16 @@ end
 
 function adcensus.writePFM(img, fname)                       -- adcensus.cu:1706-1721
    check(lib.mc_write_pfm(hostptr(img, 'writePFM'), img:size(1), img:size(2), fname), 'writePFM')
+end
+
+function adcensus.grey2jet(grey_img, col_img)                -- adcensus.cu:2000-2053 (torch.DoubleTensor arguments; main.lua:503,1242,1260)
+   for _, t in ipairs({grey_img, col_img}) do
+      if torch.typename(t) ~= 'torch.DoubleTensor' then error('grey2jet: torch.DoubleTensor expected, got ' .. (torch.typename(t) or type(t)), 2) end
+      if not t:isContiguous() then error('grey2jet: contiguous tensor expected', 2) end
+   end
+   assert(grey_img:nDimension() == 2)
+   if 3 * grey_img:nElement() ~= col_img:nElement() then error('Size mismatch', 2) end
+   check(lib.mc_grey2jet(grey_img:data(), col_img:data(), grey_img:size(1), grey_img:size(2)), 'grey2jet')
 end
 
 -- NEW entry (no counterpart in libadcensus): the whole of stereo_predict (main.lua:929-1082) from the cost-volume stage

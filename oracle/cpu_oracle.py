@@ -238,6 +238,28 @@ def fc_stack(featL, featR, D, layers):
     return vl, vr
 
 
+def grey2jet(grey):
+    """adcensus.grey2jet, /root/reference/adcensus.cu:2000-2053 (host code in the reference; the debug images of main.lua:503,1242,1260):
+    (H,W) float64 -> (3,H,W) float64, the five linear pieces of the jet map over val = 4 * grey, evaluated in doubles in the reference's
+    expressions; raises ValueError where the reference asserts (val outside [-0.1, 4.1], NaN)."""
+    g = np.ascontiguousarray(grey, np.float64)
+    val = g * 4
+    r, gg, b = np.zeros_like(val), np.zeros_like(val), np.zeros_like(val)
+    p1 = (-0.1 <= val) & (val < 0.5)
+    p2 = (0.5 <= val) & (val < 1.5)
+    p3 = (1.5 <= val) & (val < 2.5)
+    p4 = (2.5 <= val) & (val < 3.5)
+    p5 = (3.5 <= val) & (val <= 4.1)
+    if not (p1 | p2 | p3 | p4 | p5).all():
+        raise ValueError("grey2jet: val outside [-0.1, 4.1] (adcensus.cu:2046-2047 asserts)")
+    b[p1] = 0.5 + val[p1]                                   # adcensus.cu:2022-2025
+    gg[p2] = val[p2] - 0.5; b[p2] = 1                       # :2026-2029
+    r[p3] = val[p3] - 1.5; gg[p3] = 1; b[p3] = 1 - (val[p3] - 1.5)   # :2030-2033
+    r[p4] = 1; gg[p4] = 1 - (val[p4] - 2.5)                 # :2034-2037
+    r[p5] = 1 - (val[p5] - 3.5)                             # :2038-2041
+    return np.stack([r, gg, b])
+
+
 def make_params(d):
     p = OracleParams()
     term = {"": 0, "cnn": 1, "cbca1": 2, "sgm": 3, "cbca2": 4, "occlusion": 5, "mismatch": 6,

@@ -32,7 +32,7 @@ def test_only_the_abi_is_exported(mc):
 
 
 def test_version_and_struct_layout(mc):
-    assert mc._lib.lib.mc_version() == 7
+    assert mc._lib.lib.mc_version() == 8
     # mc_params is plain C: 4-byte fields, one double (8-aligned)
     assert C.sizeof(mc.params.McParams) == 88
 
