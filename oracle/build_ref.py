@@ -28,6 +28,7 @@ def build(force=False):
         return os.path.exists(OUT)
     deps = [src, os.path.join(REF, "SpatialLogSoftMax.cu"), os.path.join(HERE, "ref_shim.hip")]
     deps += [os.path.join(HERE, "ref_stubs", f) for f in os.listdir(os.path.join(HERE, "ref_stubs")) if f.endswith(".h")]
+    deps.append(os.path.join(HERE, "ref_stubs", "png++", "image.hpp"))
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return True
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
