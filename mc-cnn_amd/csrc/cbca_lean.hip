@@ -747,10 +747,19 @@ __device__ __forceinline__ float second_pass_small(const LeanArgs &A, const __am
 	const int u = (int)(b0 & 3u), rows = on ? u + (int)((b0 >> 2) & 3u) + 1 : 0;
 	float t[4][4];
 	int nn[4];
+	// MC_LEAN2X_ROW_CALLS 0 (the product): first_pass_row once per support-row INDEX at which any lane's row lies outside the tile (a wave of a
+	// texture: two to three of the four).  1 (built, NOT yet measured or run on a GPU -- a lead of DESIGN section 7): every lane brings its own
+	// first outside row to ONE call, a further round only while a lane has another.
+#ifndef MC_LEAN2X_ROW_CALLS
+#define MC_LEAN2X_ROW_CALLS 0
+#endif
+	int ls[4];
+	cb_u32 needs = 0;   // bit k: row k of this lane's support lies (partly) outside the tile
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
 		const cb_u32 lr = entry_byte(e, 1 + k);
 		const int l = (int)(lr & 15u);
+		ls[k] = l;
 		nn[k] = k < rows ? l + (int)(lr >> 4) + 1 : 0;
 		const int yy = y + k - u, ry = yy - (y0 - 1), cx0 = x - l - xb;
 		const bool inside = (unsigned)ry < (unsigned)(R + 2) && cx0 >= 1 && cx0 + nn[k] - 1 <= 254;
@@ -758,8 +767,26 @@ __device__ __forceinline__ float second_pass_small(const LeanArgs &A, const __am
 #pragma unroll
 		for (int c = 0; c < 4; ++c) t[k][c] = T[c < nn[k] ? base + c : 0];
 		const bool need = nn[k] > 0 && !inside;
-		if (__any(need)) {
-			if (need) first_pass_row(A, rv, rp0, rp1, sh, yy, x - l, nn[k], t[k]);
+		if (MC_LEAN2X_ROW_CALLS == 0) {
+			if (__any(need)) {
+				if (need) first_pass_row(A, rv, rp0, rp1, sh, yy, x - l, nn[k], t[k]);
+			}
+		} else if (need) needs |= 1u << k;
+	}
+	if (MC_LEAN2X_ROW_CALLS == 1) {
+		while (__any(needs != 0u)) {
+			const int kn = needs ? __builtin_ctz(needs) : -1;
+			int ln = 0, nk = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { ln = kn == k ? ls[k] : ln; nk = kn == k ? nn[k] : nk; }
+			float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+			if (kn >= 0) first_pass_row(A, rv, rp0, rp1, sh, y + kn - u, x - ln, nk, o);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+#pragma unroll
+				for (int c = 0; c < 4; ++c) t[k][c] = kn == k ? o[c] : t[k][c];
+			}
+			if (kn >= 0) needs &= needs - 1u;
 		}
 	}
 	float sum = 0;
