@@ -54,6 +54,28 @@ bool write_chunk(FILE *f, const char type[4], const unsigned char *data, size_t 
 
 }  // namespace
 
+namespace {
+enum JetForm { JET_ZERO, JET_ONE, JET_UP, JET_DOWN };
+struct JetChannel { JetForm form; double a; };
+struct JetPiece { double lo, hi; bool hi_closed; JetChannel ch[3]; };   // lo <= val < hi (the last piece: <= hi)
+const JetPiece JET[5] = {
+	{-0.1, 0.5, false, {{JET_ZERO, 0}, {JET_ZERO, 0}, {JET_UP, -0.5}}},     // adcensus.cu:2022-2025
+	{0.5, 1.5, false, {{JET_ZERO, 0}, {JET_UP, 0.5}, {JET_ONE, 0}}},        // :2026-2029
+	{1.5, 2.5, false, {{JET_UP, 1.5}, {JET_ONE, 0}, {JET_DOWN, 1.5}}},      // :2030-2033
+	{2.5, 3.5, false, {{JET_ONE, 0}, {JET_DOWN, 2.5}, {JET_ZERO, 0}}},      // :2034-2037
+	{3.5, 4.1, true, {{JET_DOWN, 3.5}, {JET_ZERO, 0}, {JET_ZERO, 0}}},      // :2038-2041
+};
+double jet_value(const JetChannel &c, double val)
+{
+	switch (c.form) {
+	case JET_ONE: return 1;
+	case JET_UP: return val - c.a;
+	case JET_DOWN: return 1 - (val - c.a);
+	default: return 0;
+	}
+}
+}  // namespace
+
 extern "C" {
 
 // adcensus.readPNG16(img, fname), adcensus.cu:1670-1686: img[i * width + j] = val == 0 ? 0.0 : val / 256.0 (float).
@@ -178,38 +200,25 @@ int mc_write_pfm(const float *img, int height, int width, const char *fname)
 	return 0;
 }
 
-// adcensus.grey2jet(grey_img, col_img), adcensus.cu:2000-2053: the jet colour map in five linear pieces of val = 4 * grey, doubles,
-// planes red / green / blue.  The reference asserts on a value outside [-0.1, 4.1]; here: an error with the pixel named.
+// adcensus.grey2jet(grey_img, col_img), adcensus.cu:2000-2053: the jet colour map over val = 4 * grey, doubles, planes red / green / blue.
+// The map is five pieces of val, on each of which a channel is 0, 1, a ramp up `val - a` or a ramp down `1 - (val - a)` -- held here as a
+// table and evaluated in the reference's expressions (its `0.5 + val` of the first piece is `val - (-0.5)`: the same double).  The
+// reference asserts on a value outside [-0.1, 4.1]; here: an error with the pixel named, the pixels before it written as there.
+
 int mc_grey2jet(const double *grey, double *col, int height, int width)
 {
 	if (!grey || !col || height < 1 || width < 1) { set_error("mc_grey2jet: bad argument"); return MC_EINVAL; }
 	const size_t hw = (size_t)height * width;
-	for (int i = 0; i < height; i++) {
-		for (int j = 0; j < width; j++) {
-			const double val = grey[(size_t)i * width + j] * 4;
-			double r = 0, g = 0, b = 0;
-			if (-0.1 <= val && val < 0.5) {
-				b = 0.5 + val;
-			} else if (0.5 <= val && val < 1.5) {
-				g = val - 0.5;
-				b = 1;
-			} else if (1.5 <= val && val < 2.5) {
-				r = val - 1.5;
-				g = 1;
-				b = 1 - (val - 1.5);
-			} else if (2.5 <= val && val < 3.5) {
-				r = 1;
-				g = 1 - (val - 2.5);
-			} else if (3.5 <= val && val <= 4.1) {
-				r = 1 - (val - 3.5);
-			} else {
-				set_error("mc_grey2jet: val = %f at (%d, %d) is outside the colour map's range [-0.1, 4.1]", val, i, j);
-				return MC_EINVAL;
-			}
-			col[(size_t)i * width + j] = r;
-			col[hw + (size_t)i * width + j] = g;
-			col[2 * hw + (size_t)i * width + j] = b;
+	for (size_t px = 0; px < hw; ++px) {
+		const double val = grey[px] * 4;
+		const JetPiece *piece = nullptr;
+		for (const JetPiece &q : JET)
+			if (q.lo <= val && (q.hi_closed ? val <= q.hi : val < q.hi)) { piece = &q; break; }
+		if (!piece) {   // (NaN fails every comparison)
+			set_error("mc_grey2jet: val = %f at (%d, %d) is outside the colour map's range [-0.1, 4.1]", val, (int)(px / width), (int)(px % width));
+			return MC_EINVAL;
 		}
+		for (int c = 0; c < 3; ++c) col[c * hw + px] = jet_value(piece->ch[c], val);
 	}
 	return 0;
 }
