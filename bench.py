@@ -96,7 +96,8 @@ def pick_dominant(stage_ms, ab):
 PAIR_OF = {"kitti_fast": "sample", "kitti_slow": "sample", "kitti_slow_fc": "sample", "mb_slow": "texture", "tiny": "texture"}
 PAIR_NOTE = {"sample": "the reference's real sample pair samples/input/kittiL.png / kittiR.png (tests/golden/kitti_sample_pair.npz; mirror-tiled where the shape is not 370x1226)",
              "natural": "synthetic pair with the cross-arm statistics of the reference's real KITTI sample pair (tests/util.natural_pair)",
-             "texture": "Gaussian texture, sigma 3 px, shifted by a smooth disparity field (SURVEY 8(d) recipe, tests/util.smooth_pair)"}
+             "texture": "Gaussian texture, sigma 3 px, shifted by a smooth disparity field (SURVEY 8(d) recipe, tests/util.smooth_pair)",
+             "mixed": "the Gaussian texture with flat patches (clipped highlights, exactly constant in both images) over 15 % of the image (tests/util.mixed_pair): the regime between the two"}
 
 
 def config_key(cfg):
@@ -106,13 +107,13 @@ def config_key(cfg):
 def make_inputs(cfg, rank, device, pair=None, raw_planes=None):
     """This rank's inputs (device = None: host arrays only).  Seeds: images 1234 + rank (synthetic pairs), features 42 + rank,
     raw volumes 7 + rank -- BASELINE configs[4] is "8 Middlebury-size pairs, seeds 7 ... 14", one per GPU."""
-    from util import features, natural_pair, raw_volumes, sample_pair, smooth_pair
+    from util import features, mixed_pair, natural_pair, raw_volumes, sample_pair, smooth_pair
     preset, H, W, D, C, _ = cfg
     pair = pair or PAIR_OF[config_key(cfg)]
     if pair == "sample":   # (one real pair: every rank sees the same images; features / raw volumes are seeded per rank)
         x0, x1 = sample_pair(H, W)
     else:
-        x0, x1 = (natural_pair if pair == "natural" else smooth_pair)(H, W, D, seed=1234 + rank)
+        x0, x1 = {"natural": natural_pair, "mixed": mixed_pair}.get(pair, smooth_pair)(H, W, D, seed=1234 + rank)
     host = dict(x0=x0, x1=x1, seeds=dict(images=None if pair == "sample" else 1234 + rank))
     if C < 0:  # accurate net: non-negative (post-ReLU) features + a seeded FC stack (no trained nets are available)
         rng = np.random.default_rng(42 + rank)
@@ -312,13 +313,21 @@ def cbca_additions(xb, prm, D, n_planes=8):
     return taps / max(1, vox)
 
 
+def traffic_file(cfg_key):
+    """HBM bytes per launch of a configuration's kernel groups from the rocprofv3 --pmc passes of the BUILDER's evidence run (separate passes, FETCH_SIZE /
+    WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes; scripts/gpu_pmc.sh -> scripts/make_traffic_json.py): a committed constant, NOT a measurement
+    of the run that prints it -- counters cannot be collected inside a timed run.  Returns (dict, what `traffic_source` says)."""
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % cfg_key)
+    if not os.path.exists(tfile):
+        return {}, None
+    t = json.load(open(tfile))
+    return t, "profiles/traffic_%s.json: builder's PMC pass of %s (commit %s), not measured in this run" % (cfg_key, t.get("run", "its evidence run"), t.get("commit", "n/a"))
+
+
 def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None, xb=None, pair=None):
     ab = algorithmic_bytes(prm, H, W, D, max(C, 0))
     nl = launches_per_step(prm, max(C, 0), pair)
-    traffic_all = {}
-    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % cfg_key)
-    if os.path.exists(tfile):
-        traffic_all = json.load(open(tfile))
+    traffic_all, traffic_src = traffic_file(cfg_key)
     kernels = {}
     for k in ("join", "cbca", "sgm"):
         if ab[k] > 0 and acc.get(k, 0) > 0:
@@ -347,6 +356,7 @@ def roofline_record(cfg_key, prm, H, W, D, C, acc, ms_per_step, device=None, xb=
                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                # (profiles/traffic_*.json holds cbca's bytes per ITERATION; per launch like `achieved`: x the iterations a launch runs)
                traffic=(round(traffic_all[dom] * (2 * (prm["cbca_i1"] + prm["cbca_i2"]) / nl[dom])) if dom == "cbca" and traffic_all.get(dom) else traffic_all.get(dom)),
+               traffic_source=traffic_src if traffic_all.get(dom) else None,
                launches_per_step=nl[dom], algorithmic_bytes_per_launch=round(ab[dom] / nl[dom]),
                avg_launch_ms=round(acc[dom] / nl[dom], 4), kernels=kernels,
                pipeline_frac=round(ab["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
@@ -415,6 +425,41 @@ def sub_record(device, config, reps=10, pair=None):
     return rec
 
 
+def fc_stack_record(device):
+    """The accurate architecture's cost-volume stage (SURVEY 8 f-1: mc_fc_stack, fp32 MFMA) at 370x1226x228, both volumes from one pass: ONE timed
+    call after one warm-up (0.76 s each), so that the driver's default run times it once (VERDICT r4 #8); `--config kitti_slow_fc` is the full line."""
+    import torch
+    import mc_cnn_amd as mc
+    from mc_cnn_amd.fc import fc_cost_volumes
+    cfg = CONFIGS["kitti_slow_fc"]
+    preset, H, W, D, C, name = cfg
+    xb, kw, _ = make_inputs(cfg, 0, device)
+    need = mc._lib.lib.mc_fc_stack_workspace_bytes(-C, len(kw["fc_layers"]), H, W)
+    fc_ws = torch.empty(need + 16, dtype=torch.uint8, device=device)
+    times = []
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        vl, vr = fc_cost_volumes(kw["fc_feat"], kw["fc_layers"], D, workspace=fc_ws)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    dims = [w.shape[1] for w, _ in kw["fc_layers"]] + [1]
+    vox = sum(max(0, W - d) for d in range(D)) * H
+    flop = vox * 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))  # the reference's flops (main.lua:958-983)
+    ms = times[-1]
+    tf = flop / (ms * 1e-3) / 1e12
+    finite = bool(torch.isfinite(vl[0, 0, :, D:]).all().item())   # (a sanity bit, not parity: tests/test_gpu_fc.py holds the 1e-4 comparison)
+    rec = dict(workload=name, ms_per_call=round(ms, 2), warmup_ms=round(times[0], 2), timed_calls=1,
+               roofline=dict(bound="mfma", kernel="fc_stack_kernel (+ fc_project_kernel): both volumes from one pass", achieved=round(tf, 1), peak=157.3,
+                             unit="TFLOP/s", frac=round(tf / 157.3, 4), algorithmic_flops_per_launch=flop,
+                             note="fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense peak); flops = the reference's count, the executed ones are 16 % fewer"),
+               outputs_finite=finite, parity="tolerance 1e-4 against the oracle and an fp32 addmm chain: tests/test_gpu_fc.py (BLAS summation order unpinned)")
+    del xb, kw, fc_ws, vl, vr
+    torch.cuda.empty_cache()
+    return rec
+
+
 def north_star_record(device, steps=5, with_cpu=True):
     """BASELINE.json north_star: the SGM + cross-aggregation sweep at 1500x1000x256 (mb-slow parameters,
     main.lua:132-144: 2 + 16 CBCA iterations), per volume, against SURVEY 8(d)'s 47 V = 72.2 GB budget."""
@@ -466,6 +511,7 @@ def north_star_record(device, steps=5, with_cpu=True):
         rec["cpu_baseline"] = cpu_baseline(cfg, host, 64, runs=1)
     rec["realistic_pair"] = north_star_realistic(device, "natural")
     rec["realistic_pair_sample"] = north_star_realistic(device, "sample")
+    rec["mixed_pair"] = north_star_realistic(device, "mixed")
     return rec
 
 
@@ -503,12 +549,10 @@ def north_star_realistic(device, pair):
         ops_ms = round((time.perf_counter() - t0) * 1e3, 2)
     except Exception as e:
         ops_ms = "error: %s" % str(e)[:200]
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic_mb_slow_%s.json" % pair)
-    if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get("cbca")
+    tall, tsrc = traffic_file("mb_slow_%s" % pair)
+    traffic = tall.get("cbca")
     rec = dict(pair=PAIR_NOTE[pair], ms_per_pair=round(sum(acc.values()), 2), stage_ms={k: round(v, 3) for k, v in acc.items()},
-               ops_ms_per_pair=ops_ms, cbca_traffic=traffic,
+               ops_ms_per_pair=ops_ms, cbca_traffic=traffic, cbca_traffic_source=tsrc if traffic else None,
                cbca_ms_per_launch=round(acc.get("cbca", 0) / (2 * n_it), 3), cbca_additions_per_voxel=round(apv, 2),
                cbca_additions_T_per_s=round(adds / (acc["cbca"] * 1e-3) / 1e12, 3),
                cbca_frac_of_fp32_add_peak=round(adds / (acc["cbca"] * 1e-3) / FP32_ADD_PEAK, 4),
@@ -588,7 +632,7 @@ def main():
     ap.add_argument("--no-ops", action="store_true", help="skip timing the op-by-op (unchanged main.lua) route")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed block of --steps steps until this much has been timed")
     ap.add_argument("--dry-run", action="store_true", help="build this rank's inputs, print their fingerprint as JSON and exit (no GPU needed)")
-    ap.add_argument("--pair", choices=("sample", "natural", "texture"), default=None,
+    ap.add_argument("--pair", choices=("sample", "natural", "texture", "mixed"), default=None,
                     help="image pair (default per config, PAIR_OF): real-scene arm statistics or the Gaussian texture")
     args = ap.parse_args()
     if args.config is None:
@@ -829,12 +873,16 @@ def main():
         rows = args.cpu_rows or {"kitti_fast": 370, "kitti_slow": 370, "mb_slow": 64, "tiny": 48}[args.config]
         cpu = cpu_baseline(cfg, host, rows)
 
-    north = kacc = None
+    north = kacc = kfc = None
     if rank == 0 and world == 1 and args.config == "kitti_fast" and not args.no_north_star:
         del ws, xb, kw
         torch.cuda.empty_cache()
         kacc = sub_record(device, "kitti_slow", reps=10)
         north = north_star_record(device, with_cpu=not args.no_cpu_baseline)
+        try:
+            kfc = fc_stack_record(device)
+        except Exception as e:   # (a side record must not cost the line)
+            kfc = dict(error=str(e)[:300])
 
     if rank == 0:
         line = {
@@ -850,9 +898,9 @@ def main():
                        "end_to_end_ms_per_pair": round(ms_per_step, 4),
                        "north_star_record": ("the configuration BASELINE.json's north_star target is quoted on (1000x1500x256 accurate, SGM + "
                                              "cross-aggregation sweep) is the `north_star` sub-record of this line: specified texture, "
-                                             "`realistic_pair` and `realistic_pair_sample`; KITTI accurate is `kitti_accurate`") if north else None},
+                                             "`realistic_pair`, `realistic_pair_sample` and `mixed_pair`; KITTI accurate is `kitti_accurate`, its FC stack `kitti_slow_fc`") if north else None},
             "stage_ms": stage, "roofline": roof, "cpu_baseline": cpu, "verify": verify, "ops_ms_per_pair": ops_ms,
-            "multi_gpu": multi, "kitti_accurate": kacc, "north_star": north,
+            "multi_gpu": multi, "kitti_accurate": kacc, "kitti_slow_fc": kfc, "north_star": north,
         }
         print(json.dumps(line))
         sys.stdout.flush()

@@ -140,6 +140,15 @@ static int cbca_by_arms(const void *packed, const float *vin, float *vout, int D
                         const CbcaCfg &cfg = CbcaCfg())
 {
 	if (max_arm >= 0 && max_arm <= 4) return cbca_tiles(packed, vin, vout, D, H, W, direction, 4, -1, st, cfg);
+	if (cfg.planned) {
+		// mc_predict with a plan area and 5 <= L1 <= 14: ONE candidate per pass beside the texture route's own kernel (round 4: three -- both tile
+		// instances and the strip kernel, ~6 us each to stand down).  Arms <= 4 only: served by the long-arm instance; a texture whose list is
+		// unusable (flat regions next to it): the tile kernel as well, with its plan -- not the strip kernel, whose compaction passes run at the pace of
+		// the largest support
+		int rc = cbca_tiles(packed, vin, vout, D, H, W, direction, 13, CR_PLANNED_TILE13, st, cfg);
+		if (rc || cfg.lean_two_pass) return rc;   // (pairs of passes on a texture: cbca_lean2x, launched by the caller)
+		return cbca_strips(packed, vin, vout, D, H, W, direction, CR_STRIP_IF_LIST, st, cfg);
+	}
 	int rc = cbca_tiles(packed, vin, vout, D, H, W, direction, 4, CR_TILE4, st, cfg);
 	if (rc) return rc;
 	if (max_arm < 0 || max_arm <= 13) {
@@ -322,20 +331,24 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	auto cbca_iterations = [&](int n) -> int {
 		const bool packed_ok = cbca_cap <= 254 && packed_dims_ok(H, W);  // packed lengths saturate at 255
 		for (int v = 0; v < nvol; ++v) {
+			// the plan area serves whichever kernel the pair's route word picks: the tile kernel's plan (written by its first pass) or, on
+			// textures, the records of the outputs whose support is not the minimal 3 x 3 -- written HERE, before the direction's first pass
+			// (route-gated, on the device), so that every later launch finds the list's state final: usable -> cbca_lean2x per pair of passes
+			// and the strip kernel for a single one; unusable (flat regions next to the texture) -> the tile kernel
+			const bool planned = packed_ok && cplan[v] && cbca_cap > 4 && cbca_cap <= 13 && cbca_lean_fits(D, H, W, pl.cplan, true);
+			if (planned && n > 0 && !cplan_listed[v]) {
+				const int rc1 = cbca_classify(packed, cplan[v], pl.cplan, D, H, W, direction[v], CR_STRIP, 0, 0, st, true);
+				if (rc1) return rc1;
+				cplan_listed[v] = true;
+			}
 			for (int i = 0; i < n;) {
 				float *dst = other(v);
 				CbcaCfg cfg;
 				cfg.plan = cplan[v];
 				cfg.plan_bytes = pl.cplan;
-				// the plan area serves whichever kernel the pair's route word picks: the tile kernel's plan (written by its first
-				// pass) or, on textures, the list of outputs whose support is not the minimal 3 x 3 (written here, before the first pair)
-				const bool two = packed_ok && cplan[v] && cbca_cap > 4 && cbca_cap <= 13 && i + 1 < n && cbca_lean_fits(D, H, W, pl.cplan, true);
+				cfg.planned = planned;
+				const bool two = planned && i + 1 < n;
 				cfg.lean = cfg.lean_two_pass = two;   // (a single pass: the strip kernel serves the texture route itself)
-				if (two && !cplan_listed[v]) {
-					const int rc1 = cbca_classify(packed, cplan[v], pl.cplan, D, H, W, direction[v], CR_STRIP, 0, 0, st, true);
-					if (rc1) return rc1;
-					cplan_listed[v] = true;
-				}
 				float *mid = two ? bufC[v] : dst;
 				for (int half = 0; half < (two ? 2 : 1); ++half) {   // the routes that take one pass per launch
 					cfg.plan_mode = cplan[v] ? (cplan_passes[v]++ == 0 ? 1 : 2) : 0;

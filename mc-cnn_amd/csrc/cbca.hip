@@ -184,7 +184,9 @@ __global__ void __launch_bounds__(256) cbca_strip_kernel(const CbcaArgs A)
 	__shared__ cb_u32 Clist[4][CS_COLS];        // outputs that need the general loop: frame column | up << 16 | down << 24
 	if (A.route == CR_STRIP_IF_NO_LIST || A.route == CR_NOT_DIRECT_IF_NO_LIST) {   // fallback of the lean + list kernels: the pair's list did not fit (or was never written)
 		if (!cbca_gate(A.flags, A.route == CR_STRIP_IF_NO_LIST ? (int)CR_STRIP : (int)CR_NOT_DIRECT) ||
-		    list_valid((const uint32_t *)A.plan, A.D, A.H, A.W, A.direction, A.lean_rb)) return;
+		    (A.plan && list_valid((const uint32_t *)A.plan, A.D, A.H, A.W, A.direction, A.lean_rb))) return;   // (no plan area: no list)
+	} else if (A.route == CR_STRIP_IF_LIST) {   // a single pass of mc_predict's planned passes on a texture whose list is usable
+		if (!A.plan || !cbca_gate_planned(A.flags, A.route, (const uint32_t *)A.plan, A.D, A.H, A.W, A.direction, A.lean_rb)) return;
 	} else if (!cbca_gate(A.flags, A.route)) return;   // (the pair's arms call for another kernel)
 	const int lane = threadIdx.x & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: plane descriptors stay in SGPRs
@@ -456,7 +458,7 @@ int cbca_strips(const void *packed, const float *vin, float *vout, int D, int H,
 	A.flags = route >= 0 ? cs.flag : nullptr;
 	A.route = route;
 	A.plan = cfg.plan;   // (CR_STRIP_IF_NO_LIST: the list header the launch looks at)
-	A.lean_rb = cbca_lean_rows(D, H, W, cfg.lean_rb, cfg.lean_two_pass);
+	A.lean_rb = cbca_lean_rows(D, H, W, cfg.lean_rb, cfg.lean_two_pass || route == CR_STRIP_IF_LIST);   // (mc_predict's lists are the two-pass records)
 	A.gx = (int)cdiv(W, CS_STEP);
 	// output rows per strip: 40 (5 % of halo rows) unless that leaves fewer than ~16 K waves -- at KITTI size (5 strips x
 	// 228 planes) 27 and 20 rows measured 5 % faster than 40, 53 rows 18 % slower

@@ -58,7 +58,10 @@ enum { CR_TILE4 = 0,          // every arm <= 4 (L1 <= 5): tile kernel, short-ar
        CR_NOT_DIRECT = 18,                    // the forced strip kernel: any pair the packed form holds
        CR_STRIP_OR_TILE13 = 19,               // strip kernel where L1 > 14 is known: the routes of longer arms and of arms <= 13 alike
        CR_STRIP_IF_NO_LIST = 20,              // strip kernel as the fallback of the lean + list kernels (cbca_lean.hip): route CR_STRIP and no usable list
-       CR_NOT_DIRECT_IF_NO_LIST = 21 };       // ... of the forced lean + list kernels of the test hook
+       CR_NOT_DIRECT_IF_NO_LIST = 21,         // ... of the forced lean + list kernels of the test hook
+       // mc_predict's passes where it keeps a plan area and knows 5 <= L1 <= 14 (the list is classified before the first pass of a direction):
+       CR_PLANNED_TILE13 = 22,                // tile kernel, long-arm instance: the tile routes, and route CR_STRIP whose list is unusable (a texture with flat regions)
+       CR_STRIP_IF_LIST = 23 };               // strip kernel for a SINGLE pass of route CR_STRIP with a usable list (pairs of passes: cbca_lean2x)
 
 // head of the pair's plan area when the route is CR_STRIP (cbca_lean.hip): the list of outputs whose support is not the minimal 3 x 3
 enum { LH_COUNT = 0, LH_OVERFLOW = 1, LH_D = 2, LH_H = 3, LH_W = 4, LH_DIR = 5, LH_MAGIC = 6, LH_RB = 7, LH_WORDS = 64 };   // (wave table from word LH_WORDS on, then the slots)
@@ -68,6 +71,15 @@ __device__ __forceinline__ bool list_valid(const uint32_t *__restrict__ hdr, int
 {
 	return hdr[LH_MAGIC] == LH_MAGIC_VALUE && hdr[LH_D] == (uint32_t)D && hdr[LH_H] == (uint32_t)H && hdr[LH_W] == (uint32_t)W &&
 	       hdr[LH_DIR] == (uint32_t)(direction + 1) && hdr[LH_RB] == (uint32_t)rb && !hdr[LH_OVERFLOW];
+}
+
+// the launch conditions of mc_predict's planned passes (see CR_PLANNED_TILE13): hdr = the pair's plan area, whose first LH_WORDS words are the list's head
+__device__ __forceinline__ bool cbca_gate_planned(const uint32_t *__restrict__ flags, int route, const uint32_t *__restrict__ hdr, int D, int H, int W,
+                                                  int direction, int rb)
+{
+	const uint32_t r = flags[CF_ROUTE];
+	if (route == CR_PLANNED_TILE13) return r == CR_TILE13 || r == CR_TILE4 || (r == CR_STRIP && !flags[CF_ARM_GT13] && !list_valid(hdr, D, H, W, direction, rb));
+	return r == CR_STRIP && list_valid(hdr, D, H, W, direction, rb);   // CR_STRIP_IF_LIST
 }
 
 // does this launch run? (flags == nullptr: the caller knows the arms and launched exactly the right kernel)

@@ -1087,6 +1087,13 @@ __global__ void __launch_bounds__(256) cbca_list_cost_kernel(const LeanArgs A, i
 	if (tid == 0 && !(wsum[0] + wsum[1] + wsum[2] + wsum[3] <= A.cost_limit * (float)A.H * (float)A.W)) A.hdr[LH_OVERFLOW] = 1u;
 }
 
+// before a classification: the head of the plan area back to "no list, no plan" -- if this pair is classified at all
+__global__ void __launch_bounds__(64) cbca_list_reset_kernel(const LeanArgs A)
+{
+	if (!cbca_gate(A.flags, A.route)) return;
+	if (threadIdx.x < LH_WORDS) A.hdr[threadIdx.x] = 0u;
+}
+
 // rows per wave / launch variant mc_predict uses (cfg.lean_rb = 0 / cfg.lean_variant < 0): measured at 1000 x 1500 x 256, one box
 // (profiles/r04_cbca_lean.txt): 8 rows 0.602 / 0.620 ms (address order / a band per XCD), 4 rows 0.601 / 0.601, 2 rows 0.652 / 0.635;
 // the classification costs 0.54 / 0.88 / 1.3 ms per direction
@@ -1172,11 +1179,10 @@ int cbca_classify(const void *packed, void *plan, size_t plan_bytes, int D, int 
 {
 	LeanArgs A = lean_args(packed, plan, plan_bytes, nullptr, nullptr, D, H, W, direction, route, rb, cap_limit, 0, two_pass);
 	A.cost_limit = cost_limit > 0 ? cost_limit : MC_LEAN2X_COST;
-	const hipError_t e = hipMemsetAsync(plan, 0, LH_WORDS * 4, st);   // (the header: magic and overflow word; the wave table is written in full)
-	if (e != hipSuccess) {
-		set_error("cbca_classify: %s", hipGetErrorString(e));
-		return (int)e;
-	}
+	// the head of the area -- the list's magic and overflow word, and the head of a tile kernel's plan of an earlier pair -- is cleared ON THE
+	// DEVICE under the launch condition of the classification itself: a pair whose route is the tile kernel's keeps the plan its first pass
+	// wrote there (an unconditional memset between two aggregation stages invalidated it)
+	hipLaunchKernelGGL(cbca_list_reset_kernel, dim3(1), dim3(64), 0, st, A);
 	if (two_pass) {   // (every wave writes its own record: one launch, + the per-plane cost check)
 		if (A.capd == 0) { set_error("cbca_classify: the plan area does not hold the two-pass records"); return MC_EINVAL; }
 		hipLaunchKernelGGL(cbca_classify2x_kernel, lean_grid(A), dim3(256), 0, st, A);

@@ -190,8 +190,11 @@ __device__ __forceinline__ void tile_taps3_p(float (&v)[9], unsigned pa, int n, 
 
 // head of the plan (256 bytes): who wrote it.  A pass that reads a plan stands down unless it was written for exactly this
 // problem, direction and arm class (a reading call without its writing call, or on a cached scratch of another shape)
+// (words 32 .. 37 of the 64: the first eight are the head of the texture route's list, LH_*, which shares the area -- ADVICE r4: with overlapping
+// heads, clearing the one invalidated the other)
 constexpr int PLAN_HDR = 256;
-enum { PH_MAGIC = 0, PH_D = 1, PH_H = 2, PH_W = 3, PH_DIR = 4, PH_ARM = 5 };
+enum { PH_MAGIC = 32, PH_D = 33, PH_H = 34, PH_W = 35, PH_DIR = 36, PH_ARM = 37 };
+static_assert(PLAN_HDR == LH_WORDS * 4 && PH_MAGIC >= 8, "the plan's head and the list's head share 256 bytes, not words");
 constexpr uint32_t PH_MAGIC_VALUE = 0x504c414eu;
 __device__ __forceinline__ bool plan_valid(const CbcaArgs &P, int arm_class)
 {
@@ -492,7 +495,9 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	cb_u32 *__restrict__ GHl = (cb_u32 *)(smem + G::V_BYTES + G::M_BYTES + G::UD_BYTES + G::OUT_BYTES + G::TAB_BYTES);   // [group][key]
 	cb_u32 *__restrict__ CTRl = GHl + (MODE == 2 ? 0 : NG * NKEY);   // [0] next chunk
 
-	if (!cbca_gate(P.flags, P.route)) return;   // (the pair's arms call for another kernel)
+	if (P.route == CR_PLANNED_TILE13) {   // (mc_predict: also a texture route whose list is unusable -- flat regions next to the texture)
+		if (!cbca_gate_planned(P.flags, P.route, (const uint32_t *)P.plan, P.D, P.H, P.W, P.direction, P.lean_rb)) return;
+	} else if (!cbca_gate(P.flags, P.route)) return;   // (the pair's arms call for another kernel)
 	if (MODE == 2 && !plan_valid(P, A)) return;   // (not this problem's plan)
 	if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
 		uint32_t *h = (uint32_t *)P.plan;
@@ -897,6 +902,7 @@ static PlanLayout plan_layout(int D, int H, int W)
 	return L;
 }
 size_t cbca_lean2x_bytes(int D, int H, int W);   // cbca_lean.hip: what the texture route's two-pass records take of the same area
+int cbca_lean_rows(int D, int H, int W, int rb, bool two_pass);
 size_t cbca_plan_bytes(int D, int H, int W) { return std::max(plan_layout(D, H, W).total, cbca_lean2x_bytes(D, H, W)); }
 
 template <int A, int TW, int TH, int NWAVES, int MODE>
@@ -950,10 +956,15 @@ int cbca_tiles(const void *packed, const float *vin, float *vout, int D, int H, 
 	P.D = D; P.H = H; P.W = W; P.direction = direction;
 	P.d0 = d0; P.nd = nd;
 	P.rb = 0; P.gx = P.gy = 0; P.spr = 0;   // (regions: set by the launcher)
+	P.lean_rb = 0;
 	P.flags = route >= 0 ? cs.flag : nullptr;
 	P.route = route;
 	const int pm = cfg.plan ? cfg.plan_mode : 0;
 	P.plan = pm ? cfg.plan : nullptr;
+	if (route == CR_PLANNED_TILE13) {
+		if (!pm || arm_class != 13) { set_error("cbca_tiles: the planned route needs the plan area and the long-arm instance"); return MC_EINVAL; }
+		P.lean_rb = cbca_lean_rows(D, H, W, cfg.lean_rb, true);   // (the list head the gate looks at: the two-pass records')
+	}
 	const bool nt = cfg.nt >= 0 ? cfg.nt != 0 : (int64_t)nd * H * W * 4 > ((int64_t)768 << 20);
 	// cfg.variant selects the tile geometry (test / tuning hook; 0 = the product's choice)
 	if (arm_class <= 4) {

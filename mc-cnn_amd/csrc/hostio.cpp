@@ -27,6 +27,14 @@ struct File {
 	FILE *f;
 	explicit File(const char *name, const char *mode) : f(fopen(name, mode)) {}
 	~File() { if (f) fclose(f); }
+	bool close() { FILE *g = f; f = nullptr; return g && fclose(g) == 0; }   // (the write paths: a failed flush -- a full disk -- is a failed write)
+	long remaining()   // bytes from the current position to the end (-1: not seekable)
+	{
+		const long at = ftell(f);
+		if (at < 0 || fseek(f, 0, SEEK_END)) return -1;
+		const long end = ftell(f);
+		return (end < 0 || fseek(f, at, SEEK_SET)) ? -1 : end - at;
+	}
 };
 
 uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
@@ -79,7 +87,7 @@ double jet_value(const JetChannel &c, double val)
 extern "C" {
 
 // adcensus.readPNG16(img, fname), adcensus.cu:1670-1686: img[i * width + j] = val == 0 ? 0.0 : val / 256.0 (float).
-int mc_read_png16(const char *fname, float *img, int64_t capacity, int *height, int *width)
+static int read_png16_impl(const char *fname, float *img, int64_t capacity, int *height, int *width)
 {
 	if (!fname || !height || !width) { set_error("mc_read_png16: null argument"); return MC_EINVAL; }
 	File fp(fname, "rb");
@@ -94,7 +102,12 @@ int mc_read_png16(const char *fname, float *img, int64_t capacity, int *height, 
 		unsigned char hd[8];
 		if (fread(hd, 1, 8, fp.f) != 8) { set_error("mc_read_png16: %s: truncated", fname); return MC_EINVAL; }
 		const uint32_t n = be32(hd);
-		if (n > (1u << 30)) { set_error("mc_read_png16: %s: bad chunk length", fname); return MC_EINVAL; }
+		// (a chunk cannot be longer than what is left of the file: nothing is allocated for a length a damaged file merely claims)
+		const long left = fp.remaining();
+		if (n > (1u << 30) || (left >= 0 && (unsigned long)left < (unsigned long)n + 4)) {
+			set_error("mc_read_png16: %s: %s", fname, n > (1u << 30) ? "bad chunk length" : "truncated chunk");
+			return MC_EINVAL;
+		}
 		std::vector<unsigned char> d(n + 4);
 		if (fread(d.data(), 1, n + 4, fp.f) != n + 4) { set_error("mc_read_png16: %s: truncated chunk", fname); return MC_EINVAL; }
 		uLong crc = crc32(0L, hd + 4, 4);
@@ -156,7 +169,7 @@ int mc_read_png16(const char *fname, float *img, int64_t capacity, int *height, 
 
 // adcensus.writePNG16(img, height, width, fname), adcensus.cu:1688-1704: (uint16_t)(val < 1e-5 ? 0 : val * 256) per pixel (the
 // comparison in double, the product in float, truncation), 16-bit greyscale.
-int mc_write_png16(const float *img, int height, int width, const char *fname)
+static int write_png16_impl(const float *img, int height, int width, const char *fname)
 {
 	if (!img || !fname || height < 1 || width < 1) { set_error("mc_write_png16: bad argument"); return MC_EINVAL; }
 	const size_t stride = (size_t)width * 2;
@@ -182,7 +195,7 @@ int mc_write_png16(const float *img, int height, int width, const char *fname)
 	ihdr[8] = 16; ihdr[9] = 0; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
 	const bool ok = fwrite(PNG_SIG, 1, 8, fp.f) == 8 && write_chunk(fp.f, "IHDR", ihdr, 13) && write_chunk(fp.f, "IDAT", z.data(), zlen) &&
 	                write_chunk(fp.f, "IEND", nullptr, 0);
-	if (!ok) { set_error("mc_write_png16: write to %s failed", fname); return MC_EINVAL; }
+	if (!fp.close() || !ok) { set_error("mc_write_png16: write to %s failed", fname); return MC_EINVAL; }
 	return 0;
 }
 
@@ -193,11 +206,25 @@ int mc_write_pfm(const float *img, int height, int width, const char *fname)
 	if (!img || !fname || height < 1 || width < 1) { set_error("mc_write_pfm: bad argument"); return MC_EINVAL; }
 	File fp(fname, "wb");
 	if (!fp.f) { set_error("mc_write_pfm: cannot open %s", fname); return MC_EINVAL; }
-	if (fprintf(fp.f, "Pf\n%d %d\n-0.003922\n", width, height) < 0 || fwrite(img, 4, (size_t)height * width, fp.f) != (size_t)height * width) {
+	const bool ok = fprintf(fp.f, "Pf\n%d %d\n-0.003922\n", width, height) >= 0 && fwrite(img, 4, (size_t)height * width, fp.f) == (size_t)height * width;
+	if (!fp.close() || !ok) {
 		set_error("mc_write_pfm: write to %s failed", fname);
 		return MC_EINVAL;
 	}
 	return 0;
+}
+
+// (nothing C++ may leave through the C boundary: an allocation that fails -- the sizes come from a file -- is an error code, not an abort of the
+// LuaJIT / ctypes host)
+int mc_read_png16(const char *fname, float *img, int64_t capacity, int *height, int *width)
+{
+	try { return read_png16_impl(fname, img, capacity, height, width); }
+	catch (...) { set_error("mc_read_png16: out of memory reading %s", fname ? fname : "(null)"); return MC_EINVAL; }
+}
+int mc_write_png16(const float *img, int height, int width, const char *fname)
+{
+	try { return write_png16_impl(img, height, width, fname); }
+	catch (...) { set_error("mc_write_png16: out of memory writing %s", fname ? fname : "(null)"); return MC_EINVAL; }
 }
 
 // adcensus.grey2jet(grey_img, col_img), adcensus.cu:2000-2053: the jet colour map over val = 4 * grey, doubles, planes red / green / blue.

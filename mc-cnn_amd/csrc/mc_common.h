@@ -39,6 +39,8 @@ struct CbcaCfg {
 	bool lean = false; // route CR_STRIP is served by the lean + list kernels (cbca_lean.hip) out of the list cbca_classify wrote to *plan
 	bool lean_two_pass = false;   // ... by cbca_lean2x (two passes per launch, launched by the caller), whose list has another wave geometry: cbca_by_arms
 	                              // then launches only the kernels of the other routes and the strip kernel as that list's fallback
+	bool planned = false;         // mc_predict where it keeps a plan area and 5 <= L1 <= 14: the list was classified before the direction's first pass, and a
+	                              // pass is the tile kernel's long-arm instance (CR_PLANNED_TILE13) + for a single pass the strip kernel (CR_STRIP_IF_LIST)
 };
 
 // ---- wave64 cross-lane primitives (DPP, no LDS round trip) -------------------

@@ -418,6 +418,7 @@ int interpolate_mismatch(const float *d0, const float *outlier, float *out, int 
 {
 	const int64_t size = (int64_t)H * W;
 	MC_REQUIRE(size * 16 < ((int64_t)1 << 31), "interpolate_mismatch: %dx%d pixels x 16 rays do not fit a 32-bit index", H, W);
+	MC_REQUIRE(H < (1 << 24) && W < (1 << 24), "interpolate_mismatch: %dx%d: a side beyond the 24-bit row / column arithmetic of the ray walk", H, W);
 	hipLaunchKernelGGL(interp_mis_rays_kernel, dim3(cdiv(size * 16, 256)), dim3(256), 0, st, d0, outlier, out, (int)size, H, W);
 	return check_launch("interpolate_mismatch");
 }

@@ -252,10 +252,14 @@ function adcensus.readPNG16(img, fname)                      -- adcensus.cu:1670
 end
 
 function adcensus.writePNG16(img, height, width, fname)      -- adcensus.cu:1688-1704
+   if img:nElement() < height * width then                  -- (the reference reads past the tensor here; sizes are checked in this package)
+      error(('writePNG16: the tensor holds %d elements, %d x %d asked for'):format(img:nElement(), height, width), 2)
+   end
    check(lib.mc_write_png16(hostptr(img, 'writePNG16'), height, width, fname), 'writePNG16')
 end
 
 function adcensus.writePFM(img, fname)                       -- adcensus.cu:1706-1721
+   if img:nDimension() ~= 2 then error('writePFM: 2-D tensor expected, got ' .. img:nDimension() .. ' dimensions', 2) end
    check(lib.mc_write_pfm(hostptr(img, 'writePFM'), img:size(1), img:size(2), fname), 'writePFM')
 end
 

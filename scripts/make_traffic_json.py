@@ -18,7 +18,11 @@ def main(d, config):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean over dispatches; source: " + d}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfile = os.path.join(root, "mc-cnn_amd", "BUILD_COMMIT")   # written in the build container before the snapshot travels (the GPU box has no .git)
+    out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean over dispatches; source: " + d,
+           "run": os.path.basename(os.path.dirname(os.path.normpath(d))) or d,
+           "commit": open(cfile).read().strip() if os.path.exists(cfile) else "n/a"}
     # cbca: one ITERATION over one volume = the launches of cbca_by_arms (tile instances + strip kernel, all but one of which
     # stand down at their first instruction): summed, not averaged
     groups = {"sgm": ("sgm_pass_kernel",), "cbca": ("cbca_strip_kernel", "cbca_tile_kernel", "cbca_lean_kernel", "cbca_lean2x_kernel", "cbca_classify_kernel", "cbca_classify2x_kernel", "cbca_list_kernel", "cbca_list_cost_kernel"),
@@ -50,7 +54,7 @@ def main(d, config):
         out[g + "_kernels"] = per_kernel
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_%s.json" % config)
     json.dump(out, open(path, "w"), indent=1)
-    print(path, {k: v for k, v in out.items() if not k.endswith("_kernels") and k != "_note"})
+    print(path, {k: v for k, v in out.items() if not k.endswith("_kernels") and k not in ("_note", "run", "commit")})
 
 
 if __name__ == "__main__":

@@ -59,6 +59,40 @@ def natural_pair(H, W, D, seed=1234, sigma=40.0, tex_frac=0.25, tex_amp=0.35, se
     return normalize_image(sensor(clean)[:, :W]), normalize_image(sensor(shifted)[:, :W])
 
 
+def mixed_pair(H, W, D, seed=1234, flat_frac=0.15, patch=None, noise=0.05):
+    """The regime BETWEEN the two: smooth_pair's Gaussian texture (nearly every support the minimal 3 x 3) with flat patches --
+    clipped highlights: exactly constant in both images, no sensor noise -- covering `flat_frac` of the image (10-20 %).
+    Inside a patch every arm runs to the L1 limit, so the pair has (2 L1 - 1)^2-tap supports next to 3 x 3 ones; the right image is the
+    left one shifted by smooth_pair's disparity field, the patches with it.  patch = side of a patch in pixels (default: H / 12,
+    at least 16); patches are dropped at seeded positions until their union covers flat_frac."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    Wp = W + D
+    left = gaussian_filter(rng.standard_normal((H, Wp)), 3.0)
+    left /= left.std()
+    side = int(patch) if patch else max(16, H // 12)
+    flat = np.zeros((H, Wp), bool)
+    for _ in range(10000):
+        if flat[:, :W].mean() >= flat_frac:
+            break
+        y, x = int(rng.integers(0, max(1, H - side // 2))), int(rng.integers(0, max(1, Wp - side // 2)))
+        h, w = int(rng.integers(side // 2, side + 1)), int(rng.integers(side, 2 * side + 1))
+        flat[y:y + h, x:x + w] = True
+    level = float(left.max()) + 0.5          # one clipping level for all patches, above the texture
+    left = np.where(flat, level, left)
+    disp = gaussian_filter(rng.random((H, Wp)), 12.0)
+    disp = (disp - disp.min()) / (disp.max() - disp.min() + 1e-12) * 0.8 * (D - 1)
+    xs = np.arange(Wp)[None, :] + disp
+    x0 = np.floor(xs).astype(int).clip(0, Wp - 1)
+    x1 = (x0 + 1).clip(0, Wp - 1)
+    f = xs - np.floor(xs)
+    rows = np.arange(H)[:, None]
+    right = left[rows, x0] * (1 - f) + left[rows, x1] * f
+    rflat = flat[rows, x0] & flat[rows, x1]   # both interpolation taps inside a patch: the value is the level exactly
+    right = np.where(rflat, level, right + noise * rng.standard_normal(right.shape))
+    return normalize_image(left[:, :W]), normalize_image(right[:, :W])
+
+
 def sample_pair(H=None, W=None):
     """The reference's one real input pair (samples/input/kittiL.png / kittiR.png, 370 x 1226, 8-bit grey; committed as
     tests/golden/kitti_sample_pair.npz by tests/golden/make_sample_pair.py), normalised as main.lua:1095-1096 does.
