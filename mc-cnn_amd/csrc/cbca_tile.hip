@@ -382,6 +382,23 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 	cb_u32 extbit = 1u << ext;   // (heights <= 2 A + 4 < 32)
 	asm volatile("" : "+v"(extbit));   // (opaque: stays one compare per row)
 	const cb_u32 Ebit = 1u << E;
+#ifdef MC_TILE_EVROWS
+	// the rows at which ANY lane of the chunk has an event, once per chunk (an OR over the wave, DPP): the per-row test becomes scalar
+	cb_u32 evrows;
+	{
+		cb_u32 t = evmask;
+		t |= (cb_u32)__builtin_amdgcn_update_dpp(0, (int)t, DPP_QUAD_1032, 0xF, 0xF, false);
+		t |= (cb_u32)__builtin_amdgcn_update_dpp(0, (int)t, DPP_QUAD_2301, 0xF, 0xF, false);
+		t |= (cb_u32)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false);
+		t |= (cb_u32)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_MIRROR, 0xF, 0xF, false);
+		t |= (cb_u32)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST15, 0xA, 0xF, false);
+		t |= (cb_u32)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST31, 0xC, 0xF, false);
+		evrows = (cb_u32)__builtin_amdgcn_readlane((int)t, 63);
+	}
+#define MC_TILE_ANYEV(ibit) ((evrows & (ibit)) != 0u)
+#else
+#define MC_TILE_ANYEV(ibit) __any(evmask & (ibit))
+#endif
 	if constexpr (PIPE) {
 		// the walk, two rows in flight: while row i is summed the values of row i + 1 are on their way (requested through the
 		// run word that was fetched during row i - 1) and so is the run word of row i + 2
@@ -398,7 +415,7 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 			const cb_u32 mNN = (ibit << 2) < extbit ? mr : 0u;   // (i + 2 < ext)
 			const int n = (int)(mC >> 8);
 			const cb_u32 pa = __umul24((cb_u32)slotC, (cb_u32)(SW * 4)) + cv - (mC & 0xffu);
-			const bool anyev = __any(evmask & ibit);
+			const bool anyev = MC_TILE_ANYEV(ibit);
 			if (anyev) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
@@ -432,7 +449,7 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 			slot = slot + 1 == RR ? 0 : slot + 1;
 			const cb_u32 mr = Ml[slot * TW + c];   // the next row's run travels while this row is summed
 			mnext = (ibit << 1) < extbit ? mr : 0u;   // (i + 1 < ext)
-			const bool anyev = __any(evmask & ibit);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
+			const bool anyev = MC_TILE_ANYEV(ibit);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
 			if (anyev) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {

@@ -463,7 +463,10 @@ static void launch_pass(const SgmPassArgs &A, bool vec, hipStream_t st)
 #ifndef MC_SGM_U_UP
 #define MC_SGM_U_UP 16
 #endif
-	const int U = DIRN == 2 ? 16 : (DIRN == 3 ? MC_SGM_U_UP : MC_SGM_U_H);
+#ifndef MC_SGM_U_DOWN
+#define MC_SGM_U_DOWN 16   // (round 5, A/B on one box: profiles/r05_ab.txt -- 16 steps in flight cost 236 VGPRs, i.e. two waves per SIMD)
+#endif
+	const int U = DIRN == 2 ? MC_SGM_U_DOWN : (DIRN == 3 ? MC_SGM_U_UP : MC_SGM_U_H);
 #define MC_SGM_GO(VPL_, VEC_, U_) \
 	hipLaunchKernelGGL((sgm_pass_kernel<DIRN, VPL_, MODE, ARGMIN, VEC_, U_, DUAL, false>), grid, block, 0, st, A)
 #define MC_SGM_GO_FAR(VPL_, VEC_, U_) \

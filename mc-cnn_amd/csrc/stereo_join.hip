@@ -370,19 +370,23 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 #ifndef MC_JOIN_NT
 #define MC_JOIN_NT 2
 #endif
+// waves per block: each wave's two rings are 16 KB of LDS, so blocks of four hold a CU at 8 waves (2 per SIMD), blocks of two / one at 10
+#ifndef MC_JOIN_WPB
+#define MC_JOIN_WPB 4
+#endif
 template <int KSTEPS, int NT = MC_JOIN_NT>
-__global__ void __launch_bounds__(256) join_owner_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
+__global__ void __launch_bounds__(64 * MC_JOIN_WPB) join_owner_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
                                                          float *__restrict__ volL, float *__restrict__ volR, int C, int D, int ds,
                                                          int H, int W, int pairs_per_row)
 {
-	__shared__ __attribute__((aligned(16))) float rings[4][NT * 32 * 64];
+	__shared__ __attribute__((aligned(16))) float rings[MC_JOIN_WPB][NT * 32 * 64];
 	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	// XCD-aware mapping as in join_mfma_kernel: all blocks of one image row on one XCD
 	const int b = blockIdx.x;
 	const int xcd = b & 7, k = b >> 3;
-	const int blocks_per_row = (2 * pairs_per_row + 3) >> 2;
+	const int blocks_per_row = (2 * pairs_per_row + MC_JOIN_WPB - 1) / MC_JOIN_WPB;
 	const int y = (k / blocks_per_row) * 8 + xcd;
-	const int w = (k % blocks_per_row) * 4 + wid;
+	const int w = (k % blocks_per_row) * MC_JOIN_WPB + wid;
 	if (y >= H || w >= 2 * pairs_per_row) return;
 	if (w < pairs_per_row) join_owner_tiles<KSTEPS, 0, NT>(fL, fR, volL, C, D, ds, H, W, y, NT * w, rings[wid]);
 	else join_owner_tiles<KSTEPS, 1, NT>(fL, fR, volR, C, D, ds, H, W, y, NT * (w - pairs_per_row), rings[wid]);
@@ -412,10 +416,10 @@ int stereo_join_hwd(const float *fL, const float *fR, float *volL, float *volR, 
 	const dim3 block(256);
 	if (ds % 4 == 0 && (uintptr_t)volL % 16 == 0 && (uintptr_t)volR % 16 == 0 && ks <= 32) {
 		const int tiles_own = ((W + 31) / 32 + MC_JOIN_NT - 1) / MC_JOIN_NT;   // groups of MC_JOIN_NT 32-pixel tiles per image row and volume
-		const dim3 grid_o((unsigned)(rows8 * ((2 * tiles_own + 3) / 4) * 8));
-		if (ks <= 8) hipLaunchKernelGGL((join_owner_kernel<8>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
-		else if (ks <= 16) hipLaunchKernelGGL((join_owner_kernel<16>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
-		else hipLaunchKernelGGL((join_owner_kernel<32>), grid_o, block, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
+		const dim3 grid_o((unsigned)(rows8 * ((2 * tiles_own + MC_JOIN_WPB - 1) / MC_JOIN_WPB) * 8)), block_o(64 * MC_JOIN_WPB);
+		if (ks <= 8) hipLaunchKernelGGL((join_owner_kernel<8>), grid_o, block_o, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
+		else if (ks <= 16) hipLaunchKernelGGL((join_owner_kernel<16>), grid_o, block_o, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
+		else hipLaunchKernelGGL((join_owner_kernel<32>), grid_o, block_o, 0, st, fL, fR, volL, volR, C, D, ds, H, W, tiles_own);
 		int rc = check_launch("stereo_join_hwd (owner tiles)");
 		if (rc || n <= 0) return rc;
 		hipLaunchKernelGGL(fix_border_hwd_kernel, dim3(cdiv((int64_t)H * n * 64, 256)), block, 0, st, volL, D, ds, H, W, n, -1);
