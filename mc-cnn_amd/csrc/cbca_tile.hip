@@ -186,6 +186,50 @@ __device__ __forceinline__ void tile_taps3_p(float (&v)[9], unsigned pa, int n, 
 #undef MC_LOAD9
 #undef MC_EXIT
 
+#ifdef MC_TILE_MFMA
+// The same taps on the matrix core (round 5).  v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4 x 4 outer products, K = 1:
+// D_b[i][j] += A_b[i] * B_b[j], block b = lane / 4, A_b[i] from lane 4 b + i, B_b[j] from lane 4 b + j, and lane 4 b + j holds D_b[0 .. 3][j] in its
+// four accumulator registers.  With A = 1.0 in every lane that is: EVERY LANE adds ITS OWN value to ITS OWN four accumulators -- exactly what the four
+// v_add_f32 of a tap do, as one instruction, and bit for bit the same sums (fma(1.0, v, acc) rounds acc + v once; MI355X guide, "FP32-input MFMA": a
+// k-ordered fmaf chain, and K = 1 here).  The matrix core does not look at EXEC, so a lane whose run is over contributes -0.0 (x + -0.0 == x for every x,
+// the padding cbca_strip_kernel's window form uses): one compare, one select, one MFMA per tap instead of one compare and four additions.
+typedef float tile_f4 __attribute__((ext_vector_type(4)));
+template <bool LONG, bool PRE>
+__device__ __forceinline__ void tile_taps_m(float (&v)[9], unsigned pa, int n, tile_f4 &acc)
+{
+	const lds_cfp p = (lds_cfp)(__UINTPTR_TYPE__)pa;
+	if (!PRE) {
+#pragma unroll
+		for (int t = 0; t < 9; ++t) v[t] = p[t];
+	}
+	// (n opaque: hipcc otherwise folds the shift that produced it into 27 comparison constants and keeps them in scalar registers; hipcc interleaves the selects of a
+	// group with its MFMAs: select -> MFMA operand, MFMA -> dependent MFMA and compare -> select each want two instructions in between)
+	asm volatile("" : "+v"(n));
+#define MC_TS(t, val) ((t) < n ? (val) : -0.0f)
+#define MC_TM(x) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, (x), acc, 0, 0, 0)
+	{ const float x0 = MC_TS(0, v[0]), x1 = MC_TS(1, v[1]), x2 = MC_TS(2, v[2]); MC_TM(x0); MC_TM(x1); MC_TM(x2); }
+	if (!__any(3 < n)) return;
+	{ const float x0 = MC_TS(3, v[3]), x1 = MC_TS(4, v[4]); MC_TM(x0); MC_TM(x1); }
+	if (!__any(5 < n)) return;
+	{ const float x0 = MC_TS(5, v[5]), x1 = MC_TS(6, v[6]), x2 = MC_TS(7, v[7]), x3 = MC_TS(8, v[8]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); }
+	if (!LONG) return;
+	if (!__any(9 < n)) return;
+#pragma unroll
+	for (int t = 0; t < 9; ++t) v[t] = p[9 + t];
+	{ const float x0 = MC_TS(9, v[0]), x1 = MC_TS(10, v[1]), x2 = MC_TS(11, v[2]), x3 = MC_TS(12, v[3]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); }
+	if (!__any(13 < n)) return;
+	{ const float x0 = MC_TS(13, v[4]), x1 = MC_TS(14, v[5]), x2 = MC_TS(15, v[6]), x3 = MC_TS(16, v[7]), x4 = MC_TS(17, v[8]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); MC_TM(x4); }
+	if (!__any(18 < n)) return;
+#pragma unroll
+	for (int t = 0; t < 9; ++t) v[t] = p[18 + t];
+	{ const float x0 = MC_TS(18, v[0]), x1 = MC_TS(19, v[1]), x2 = MC_TS(20, v[2]), x3 = MC_TS(21, v[3]), x4 = MC_TS(22, v[4]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); MC_TM(x4); }
+	if (!__any(23 < n)) return;
+	{ const float x0 = MC_TS(23, v[5]), x1 = MC_TS(24, v[6]), x2 = MC_TS(25, v[7]), x3 = MC_TS(26, v[8]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); }
+#undef MC_TS
+#undef MC_TM
+}
+#endif
+
 }  // namespace
 
 // head of the plan (256 bytes): who wrote it.  A pass that reads a plan stands down unless it was written for exactly this
@@ -225,6 +269,36 @@ __device__ __forceinline__ cb_u32 tile_item_rows(const unsigned char *__restrict
 		bot = max(bot, e0[j]);
 	}
 	return udall;
+}
+
+// The first- / last-row events of a walk row (round 5): four compares into four scalar mask pairs FIRST, then the eight selects.  hipcc compiles the
+// plain form to  v_cmp (vcc), s_nop 1, two v_cndmask  per accumulator -- on gfx950 a VALU instruction that reads a mask must stand two instructions
+// behind the VALU compare that wrote it, and with every compare going through vcc nothing can fill the gap: 16 instructions per event kind and
+// row, 4 of them s_nop.  Here the gaps fill themselves: 12 instructions.
+__device__ __forceinline__ void tile_events_start(cb_u32 ibit, const cb_u32 (&sbit)[4], float (&sum)[4], int (&cb)[4], int Pn)
+{
+	unsigned long long m0, m1, m2, m3;
+	asm volatile("v_cmp_eq_u32_e64 %[m0], %[ib], %[b0]\n v_cmp_eq_u32_e64 %[m1], %[ib], %[b1]\n v_cmp_eq_u32_e64 %[m2], %[ib], %[b2]\n v_cmp_eq_u32_e64 %[m3], %[ib], %[b3]\n"
+	             " v_cndmask_b32_e64 %[s0], %[s0], 0, %[m0]\n v_cndmask_b32_e64 %[c0], %[c0], %[pn], %[m0]\n"
+	             " v_cndmask_b32_e64 %[s1], %[s1], 0, %[m1]\n v_cndmask_b32_e64 %[c1], %[c1], %[pn], %[m1]\n"
+	             " v_cndmask_b32_e64 %[s2], %[s2], 0, %[m2]\n v_cndmask_b32_e64 %[c2], %[c2], %[pn], %[m2]\n"
+	             " v_cndmask_b32_e64 %[s3], %[s3], 0, %[m3]\n v_cndmask_b32_e64 %[c3], %[c3], %[pn], %[m3]\n"
+	             : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3]),
+	               [c0] "+v"(cb[0]), [c1] "+v"(cb[1]), [c2] "+v"(cb[2]), [c3] "+v"(cb[3])
+	             : [ib] "s"(ibit), [b0] "v"(sbit[0]), [b1] "v"(sbit[1]), [b2] "v"(sbit[2]), [b3] "v"(sbit[3]), [pn] "v"(Pn));
+}
+__device__ __forceinline__ void tile_events_end(cb_u32 ibit, const cb_u32 (&ebit)[4], const float (&sum)[4], float (&res)[4], int (&ce)[4], int Pn)
+{
+	unsigned long long m0, m1, m2, m3;
+	asm volatile("v_cmp_eq_u32_e64 %[m0], %[ib], %[b0]\n v_cmp_eq_u32_e64 %[m1], %[ib], %[b1]\n v_cmp_eq_u32_e64 %[m2], %[ib], %[b2]\n v_cmp_eq_u32_e64 %[m3], %[ib], %[b3]\n"
+	             " v_cndmask_b32_e64 %[r0], %[r0], %[s0], %[m0]\n v_cndmask_b32_e64 %[c0], %[c0], %[pn], %[m0]\n"
+	             " v_cndmask_b32_e64 %[r1], %[r1], %[s1], %[m1]\n v_cndmask_b32_e64 %[c1], %[c1], %[pn], %[m1]\n"
+	             " v_cndmask_b32_e64 %[r2], %[r2], %[s2], %[m2]\n v_cndmask_b32_e64 %[c2], %[c2], %[pn], %[m2]\n"
+	             " v_cndmask_b32_e64 %[r3], %[r3], %[s3], %[m3]\n v_cndmask_b32_e64 %[c3], %[c3], %[pn], %[m3]\n"
+	             : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [r0] "+v"(res[0]), [r1] "+v"(res[1]), [r2] "+v"(res[2]), [r3] "+v"(res[3]),
+	               [c0] "+v"(ce[0]), [c1] "+v"(ce[1]), [c2] "+v"(ce[2]), [c3] "+v"(ce[3])
+	             : [ib] "s"(ibit), [b0] "v"(ebit[0]), [b1] "v"(ebit[1]), [b2] "v"(ebit[2]), [b3] "v"(ebit[3]), [pn] "v"(Pn),
+	               [s0] "v"(sum[0]), [s1] "v"(sum[1]), [s2] "v"(sum[2]), [s3] "v"(sum[3]));
 }
 
 // One work unit of a step (cbca_tile_kernel's chunk phase; window of the step = ring rows base .. base + TH + 2A - 1 mod RR):
@@ -372,7 +446,12 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 		sbit[j] = outj[j] ? 1u << (s0[j] - top) : 0u;
 		ebit[j] = outj[j] ? 1u << (e0[j] - top) : 0u;
 	}
+#ifdef MC_TILE_MFMA
+	tile_f4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+	float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#else
 	float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#endif
 	int cb[4] = {0, 0, 0, 0}, ce[4] = {1, 1, 1, 1};   // taps of the wave-row walk before the output's first row / up to its last row
 	int Pn = 0;
 	const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;   // LDS byte address of the item's column in ring slot 0
@@ -382,10 +461,17 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 	cb_u32 extbit = 1u << ext;   // (heights <= 2 A + 4 < 32)
 	asm volatile("" : "+v"(extbit));   // (opaque: stays one compare per row)
 	const cb_u32 Ebit = 1u << E;
-#ifdef MC_TILE_EVROWS
-	// the rows at which ANY lane of the chunk has an event, once per chunk (an OR over the wave, DPP): the per-row test becomes scalar
-	cb_u32 evrows;
-	{
+	// Long-arm instance (round 5, A/B on one box, profiles/r05_ab_tile.txt: 95.5 -> 93.3 -> 92.9 ms of aggregation per realistic 1000 x 1500 x 256 pair; the
+	// short-arm instance measured 0.5 % slower with either, so it keeps the plain forms): (i) the rows at which ANY lane of the chunk has an event, once
+	// per chunk (an OR over the wave, DPP) -- the per-row test becomes one scalar AND instead of v_and + v_cmp + two scalar instructions; (ii) the
+	// events as tile_events_start / tile_events_end (no wait states)
+#ifdef MC_TILE_PLAIN_EVENTS
+	constexpr bool EVFAST = false;
+#else
+	constexpr bool EVFAST = A > 4;
+#endif
+	cb_u32 evrows = 0;
+	if constexpr (EVFAST) {
 		cb_u32 t = evmask;
 		t |= (cb_u32)__builtin_amdgcn_update_dpp(0, (int)t, DPP_QUAD_1032, 0xF, 0xF, false);
 		t |= (cb_u32)__builtin_amdgcn_update_dpp(0, (int)t, DPP_QUAD_2301, 0xF, 0xF, false);
@@ -395,10 +481,7 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 		t |= (cb_u32)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST31, 0xC, 0xF, false);
 		evrows = (cb_u32)__builtin_amdgcn_readlane((int)t, 63);
 	}
-#define MC_TILE_ANYEV(ibit) ((evrows & (ibit)) != 0u)
-#else
-#define MC_TILE_ANYEV(ibit) __any(evmask & (ibit))
-#endif
+#define MC_TILE_ANYEV(ibit) (EVFAST ? (evrows & (ibit)) != 0u : (bool)__any(evmask & (ibit)))
 	if constexpr (PIPE) {
 		// the walk, two rows in flight: while row i is summed the values of row i + 1 are on their way (requested through the
 		// run word that was fetched during row i - 1) and so is the run word of row i + 2
@@ -417,6 +500,10 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 			const cb_u32 pa = __umul24((cb_u32)slotC, (cb_u32)(SW * 4)) + cv - (mC & 0xffu);
 			const bool anyev = MC_TILE_ANYEV(ibit);
 			if (anyev) {
+#ifndef MC_TILE_MFMA
+				if constexpr (EVFAST) tile_events_start(ibit, sbit, sum, cb, Pn);
+				else
+#endif
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const bool st = sbit[j] == ibit;
@@ -424,9 +511,17 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 					cb[j] = st ? Pn : cb[j];
 				}
 			}
+#ifdef MC_TILE_MFMA
+			tile_taps_m<(A > 4), true>(cur, pa, n, sum);
+#else
 			tile_taps_p<(A > 4)>(cur, pa, n, sum);
+#endif
 			Pn += n;
 			if (anyev) {
+#ifndef MC_TILE_MFMA
+				if constexpr (EVFAST) tile_events_end(ibit, ebit, sum, res, ce, Pn);
+				else
+#endif
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const bool en = ebit[j] == ibit;
@@ -451,6 +546,10 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 			mnext = (ibit << 1) < extbit ? mr : 0u;   // (i + 1 < ext)
 			const bool anyev = MC_TILE_ANYEV(ibit);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
 			if (anyev) {
+#ifndef MC_TILE_MFMA
+				if constexpr (EVFAST) tile_events_start(ibit, sbit, sum, cb, Pn);
+				else
+#endif
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const bool st = sbit[j] == ibit;   // the output's first row: its chain starts from +0.0 here
@@ -458,9 +557,18 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 					cb[j] = st ? Pn : cb[j];
 				}
 			}
+#ifdef MC_TILE_MFMA
+			float vm[9];
+			tile_taps_m<(A > 4), false>(vm, pa, n, sum);
+#else
 			tile_taps<(A > 4)>(pa, n, sum);
+#endif
 			Pn += n;
 			if (anyev) {
+#ifndef MC_TILE_MFMA
+				if constexpr (EVFAST) tile_events_end(ibit, ebit, sum, res, ce, Pn);
+				else
+#endif
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const bool en = ebit[j] == ibit;   // the output's last row
