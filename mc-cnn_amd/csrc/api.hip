@@ -60,7 +60,7 @@ int sgm_prep(const float *x0, const float *x1, void *maps, int H, int W, float t
 int sgm_contract_violations(const float *vol, int H, int W, int D, unsigned *count, hipStream_t st);
 int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2], float *const disp[2],
                const int direction[2], int nvol, int H, int W, int D, int ds, const void *maps, float pi1, float pi2,
-               float alpha1, float q1, float q2, bool fused, hipStream_t st);
+               float alpha1, float q1, float q2, bool fused, hipStream_t st, float *const out3[2] = nullptr);
 
 static thread_local char g_err[512] = "";
 
@@ -216,7 +216,12 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	const StageCounts sc = stage_counts(p);
 	pl.cplan = (sc.cbca1 + sc.cbca2 >= 2 && p->L1 - 1 <= 13) ? align_up(cbca_plan_bytes(D, H, W), 256) : 0;
 	pl.nplan = (p->left_only && !p->lr_check) ? 1 : 2;
-	pl.total = pl.maps + pl.arms + pl.pack + 6 * pl.vol + 6 * pl.img + pl.gk + pl.nplan * pl.cplan;
+#ifdef MC_SGM_SCHEDULE_R5
+	constexpr int NVOLS = 8;   // + the down sweep's partial sums per side (sgm.hip: measured, not the product)
+#else
+	constexpr int NVOLS = 6;   // ping-pong per side (4) + the left sweep's partial sums per side
+#endif
+	pl.total = pl.maps + pl.arms + pl.pack + NVOLS * pl.vol + 6 * pl.img + pl.gk + pl.nplan * pl.cplan;
 	return pl;
 }
 
@@ -286,6 +291,11 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	float *bufC[2];  // scratch of the SGM's concurrent second direction
 	bufC[0] = (float *)w; w += pl.vol;
 	bufC[1] = (float *)w; w += pl.vol;
+#ifdef MC_SGM_SCHEDULE_R5
+	float *bufD[2];  // ... and of the down sweep that runs beside the horizontal ones
+	bufD[0] = (float *)w; w += pl.vol;
+	bufD[1] = (float *)w; w += pl.vol;
+#endif
 	float *img[6];
 	for (int i = 0; i < 6; ++i) { img[i] = (float *)w; w += pl.img; }
 	float *gk = (float *)w; w += pl.gk;
@@ -414,7 +424,11 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 			float *outv[2] = {other(0), other(1)};
 			const bool am = (it == n_sgm - 1) && n_cbca2 == 0;
 			RUN(sgm_sweeps(Cv, outv, bufC, am ? dispv : nullptr, direction, nvol, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
-			               p->sgm_q1, p->sgm_q2, true, st));
+#ifdef MC_SGM_SCHEDULE_R5
+			               p->sgm_q1, p->sgm_q2, true, st, bufD));
+#else
+			               p->sgm_q1, p->sgm_q2, true, st, nullptr));
+#endif
 			have_disp = am;
 			cur[0] = outv[0]; cur[1] = outv[1];
 		}
