@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import mc_cnn_amd as mc
 from oracle import cpu_oracle as oracle
-from util import smooth_pair, blocky_pair, random_pair, natural_pair, features, raw_volumes  # noqa: E402
+from util import smooth_pair, blocky_pair, random_pair, natural_pair, mixed_pair, features, raw_volumes  # noqa: E402
 
 from util import same_bits as same
 
@@ -24,16 +24,20 @@ for it in range(n):
     H = int(rng.integers(3, 40 if big_d else 90))
     W = int(rng.integers(6, 120 if big_d else 560))
     D = int(rng.integers(2, min(W, 300 if big_d else 70)))
-    prm["cbca_i1"] = int(min(prm["cbca_i1"], 2)); prm["cbca_i2"] = int(min(prm["cbca_i2"], 3))
+    # aggregation pass counts: any of 0 .. 3 before and 0 .. 5 after the SGM where the table aggregates at all (round 5; ADVICE r4: the counts were clamped
+    # to the tables' 0 / 2, so a single first pass followed by pairs never ran)
+    if prm["cbca_i1"] + prm["cbca_i2"] > 0:
+        prm["cbca_i1"] = int(rng.integers(0, 4)); prm["cbca_i2"] = int(rng.integers(0, 6))
     if rng.random() < 0.3:
         prm["sm_terminate"] = ["", "cnn", "cbca1", "sgm", "cbca2", "subpixel_enchancement", "median", "bilateral"][rng.integers(8)]
     if rng.random() < 0.3:
         prm["sm_skip"] = ["", "cbca", "sgm", "occlusion", "subpixel_enchancement", "median", "bilateral"][rng.integers(7)]
-    kind = ["smooth", "blocky", "random", "natural", "natural"][rng.integers(5)]
+    kind = ["smooth", "blocky", "random", "natural", "natural", "mixed"][rng.integers(6)]
     if rng.random() < 0.25:   # arm limits between the parameter tables' (tile kernel short- / long-arm instance boundary at L1 = 5 | 6, strip kernel beyond 14)
         prm["L1"] = int(rng.integers(0, 20)); prm["tau1"] = float(rng.choice([0.02, 0.13, 0.5, 3.0]))
     x0, x1 = (smooth_pair(H, W, min(D, 8), seed=it) if kind == "smooth" else blocky_pair(H, W, seed=it) if kind == "blocky"
               else natural_pair(H, W, min(D, 8), seed=it, sigma=float(rng.choice([6.0, 15.0, 40.0]))) if kind == "natural"
+              else mixed_pair(H, W, min(D, 8), seed=it, flat_frac=float(rng.choice([0.04, 0.15])), patch=max(8, H // 3)) if kind == "mixed"
               else random_pair(H, W, seed=it))
     xb = torch.from_numpy(np.stack([x0, x1])).cuda()[:, None]
     from_feat = rng.random() < 0.5
