@@ -50,7 +50,8 @@ def test_cbca_plane_range(mc, oracle):
 
 
 @pytest.mark.parametrize("nt", [0, 1])
-@pytest.mark.parametrize("R,Cn", [(228, 370 * 7), (65, 129), (256, 1000), (228, 2592), (4, 8), (68, 132), (228, 453620 // 19)])   # (16-byte and 4-byte paths)
+@pytest.mark.parametrize("R,Cn", [(228, 370 * 7), (65, 129), (256, 1000), (228, 2592), (4, 8), (68, 132), (228, 453620 // 19),
+                                  (248, 640), (72, 64), (100, 4100), (12, 256), (252, 128)])   # (16-byte and 4-byte paths; round 5: whole-run kernel for short rows off the 128-byte grid)
 def test_transposes_forced_cache_policy(mc, R, Cn, nt):
     rng = np.random.default_rng(R)
     a = rng.standard_normal((R, Cn)).astype(np.float32)
@@ -58,6 +59,20 @@ def test_transposes_forced_cache_policy(mc, R, Cn, nt):
     out = torch.empty((Cn, R), device="cuda")
     mc.adcensus.transpose_cfg(dev(a), out, R, Cn, Cn, R, scale=0.25, nt=nt)
     assert same_bits(out.cpu().numpy(), (a * np.float32(0.25)).T)
+
+
+@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("R,Cn,ld", [(70, 1300, 72), (229, 260, 232), (228, 4000, 228), (13, 64, 16), (228, 64, 256), (9, 68, 12), (8, 4096, 8)])
+def test_transpose_whole_runs_with_padded_rows(mc, R, Cn, ld, nt):
+    """(D,H,W) -> (H,W,ds) as mc_predict does it: output rows of ds = D rounded up to 4 floats, the padding never written"""
+    rng = np.random.default_rng(R + Cn)
+    a = rng.standard_normal((R, Cn)).astype(np.float32)
+    a[R // 2, ::7] = np.nan
+    out = torch.full((Cn, ld), -7.0, device="cuda")
+    mc.adcensus.transpose_cfg(dev(a), out, R, Cn, Cn, ld, scale=1.0, nt=nt)
+    got = out.cpu().numpy()
+    assert same_bits(got[:, :R], a.T)
+    assert (got[:, R:] == -7.0).all(), "the padding behind a run was written"
 
 
 def test_left_only_skips_the_right_volume_without_changing_the_left(mc):
