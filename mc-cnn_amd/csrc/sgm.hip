@@ -257,18 +257,36 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 		}
 	};
 
+	// MC_SGM_DBG (timing experiments only, results wrong): bit 0 no volume stores, bit 1 no window-class loads, bit 2 no reference-class loads,
+	// bit 3 no cost loads, bit 4 no wave-wide minimum
+#ifndef MC_SGM_DBG
+#define MC_SGM_DBG 0
+#endif
 	auto load_step = [&](StepData<VPL, NACC> &sd, int s) {
 		const unsigned so = c0v + (unsigned)s * c1v;
 		const int64_t pix = FAR ? (int64_t)(y0s + s * sy) * W + (x0s + s * sx) : 0;
+		if (MC_SGM_DBG & 8) {
+#pragma unroll
+			for (int j = 0; j < VPL; ++j) sd.c[j] = 1.0f;
+		} else
 		load_run(sd.c, Cp, rC, so, pix);
 		if constexpr (NACC >= 1) load_run(sd.a, Ain, rA, so, pix);
 		if constexpr (NACC >= 2) load_run(sd.a2, Ain2, rA2, so, pix);
 		if constexpr (NACC >= 3) load_run(sd.a3, Ain3, rA3, so, pix);
 		unsigned pk = 0;
 		const unsigned sw = (unsigned)(w0 + s * dw);
+		if (!(MC_SGM_DBG & 2)) {
 #pragma unroll
-		for (int q = 0; q < VPL / 4; ++q) pk |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rW, woff + q * wq, sw, 0) << (8 * q);
+			for (int q = 0; q < VPL / 4; ++q) pk |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rW, woff + q * wq, sw, 0) << (8 * q);
+		} else {
+			pk = 0x55u;
+			asm volatile("" : "+v"(pk));
+		}
 		sd.pk = pk;
+		if (MC_SGM_DBG & 4) {
+			sd.a0 = 1u;
+			asm volatile("" : "+v"(sd.a0));
+		} else
 		sd.a0 = __builtin_amdgcn_raw_buffer_load_b8(rCls, 0, (unsigned)(pix0 + s * dp), 0);  // every lane reads the same byte
 	};
 
@@ -282,7 +300,7 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 				uint4v t;
 				t.x = __float_as_uint(o[4 * q + 0]); t.y = __float_as_uint(o[4 * q + 1]);
 				t.z = __float_as_uint(o[4 * q + 2]); t.w = __float_as_uint(o[4 * q + 3]);
-				__builtin_amdgcn_raw_buffer_store_b128(t, r, lane_off[q], soff, MC_SGM_VOL_AUX);
+				__builtin_amdgcn_raw_buffer_store_b128(t, r, (MC_SGM_DBG & 1) ? OOBV : lane_off[q], soff, MC_SGM_VOL_AUX);
 			}
 		} else {
 #pragma unroll
@@ -376,6 +394,9 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 		float nm = vmin3(prev[0], prev[1], prev[2]);
 #pragma unroll
 		for (int j = 3; j < VPL; j += 2) nm = j + 1 < VPL ? vmin3(nm, prev[j], prev[j + 1]) : vmin2(nm, prev[j]);
+		if (MC_SGM_DBG & 16) {
+			m = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(nm)));
+		} else
 		m = wave_min_q(nm);
 		store_step(o, s);
 	};
