@@ -24,6 +24,9 @@
 // cache policy of the volume accesses: nt (bit 1) -- every cost run is read or written once per sweep; streaming them keeps
 // the edge-class maps (re-read by every line) in L2
 #define MC_SGM_VOL_AUX 2
+#ifndef MC_SGM_ST_AUX
+#define MC_SGM_ST_AUX MC_SGM_VOL_AUX   // (the stores' policy on its own: round 5 A/B)
+#endif
 
 namespace mc {
 
@@ -300,7 +303,7 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 				uint4v t;
 				t.x = __float_as_uint(o[4 * q + 0]); t.y = __float_as_uint(o[4 * q + 1]);
 				t.z = __float_as_uint(o[4 * q + 2]); t.w = __float_as_uint(o[4 * q + 3]);
-				__builtin_amdgcn_raw_buffer_store_b128(t, r, (MC_SGM_DBG & 1) ? OOBV : lane_off[q], soff, MC_SGM_VOL_AUX);
+				__builtin_amdgcn_raw_buffer_store_b128(t, r, (MC_SGM_DBG & 1) ? OOBV : lane_off[q], soff, MC_SGM_ST_AUX);
 			}
 		} else {
 #pragma unroll
