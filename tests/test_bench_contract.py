@@ -141,3 +141,18 @@ def test_texture_route_launches_run_two_iterations_each():
         per_it = json.load(open(tfile))["cbca"]
         assert rec["traffic"] == round(per_it * 2)
         assert rec["traffic"] < rec["algorithmic_bytes_per_launch"]   # the point of the kernel: fewer bytes moved than the count
+
+
+def test_traffic_files_say_where_their_numbers_come_from():
+    """`roofline.traffic` is a builder-kept constant (a rocprofv3 --pmc pass of the evidence run), and the record must say so: every
+    committed profiles/traffic_<config>.json is stamped with the run and the commit it was collected on, and bench.py turns that into `traffic_source`"""
+    import glob
+    import bench
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "profiles", "traffic_*.json")))
+    assert len(files) >= 6
+    for f in files:
+        key = os.path.basename(f)[len("traffic_"):-len(".json")]
+        t, src = bench.traffic_file(key)
+        assert t.get("run") and t.get("commit") and t["commit"] != "n/a", f
+        assert src.startswith("profiles/traffic_%s.json" % key) and "not measured in this run" in src and t["commit"] in src
+    assert bench.traffic_file("no_such_config") == ({}, None)

@@ -1,7 +1,7 @@
 """The synthetic image pairs of bench.py / the tests: their cross-arm statistics are what decides the cost of cbca."""
 import numpy as np
 
-from util import natural_pair, sample_pair, smooth_pair
+from util import mixed_pair, natural_pair, sample_pair, smooth_pair
 
 
 def arm_lengths(oracle, x, L1, tau1):
@@ -36,6 +36,28 @@ def test_smooth_pair_is_the_textured_extreme(oracle):
     x0, x1 = smooth_pair(120, 400, 32, seed=3)
     a = np.minimum(arm_lengths(oracle, x0, 14, 0.02), arm_lengths(oracle, x1, 14, 0.02))
     assert non_minimal_share(a) < 0.1 and a.max() <= 13
+
+
+def test_mixed_pair_is_a_texture_with_flat_patches(oracle):
+    """tests/util.mixed_pair (bench.py's `north_star.mixed_pair`): the Gaussian texture's minimal supports outside the patches, arms at the
+    L1 - 1 limit inside them (exactly constant in BOTH images), the patches over the asked share of the image; seeded"""
+    H, W, D = 300, 900, 64
+    x0, x1 = mixed_pair(H, W, D, seed=7, flat_frac=0.15)
+    y0, y1 = mixed_pair(H, W, D, seed=7, flat_frac=0.15)
+    assert np.array_equal(x0, y0) and np.array_equal(x1, y1)
+    assert abs(x0.mean()) < 1e-3 and abs(x0.std() - 1) < 1e-2 and x0.dtype == np.float32
+    flat = x0 == x0.max()                                    # (the patches are the clipping level)
+    assert 0.14 < flat.mean() < 0.25
+    a0, a1 = arm_lengths(oracle, x0, 14, 0.02), arm_lengths(oracle, x1, 14, 0.02)
+    from scipy.ndimage import binary_erosion
+    deep = binary_erosion(flat, structure=np.ones((27, 27), bool))   # 13 flat pixels in every direction: all four arms of the left image at the limit
+    assert deep.any() and (a0[:, deep] == 13).all()
+    assert (a1 == 13).mean() > 0.02                          # ... and the right image has them too (shifted)
+    tex = ~flat
+    tex[:2] = tex[-2:] = False; tex[:, :2] = tex[:, -2:] = False
+    assert (a0[:, tex] == 1).mean() > 0.8                    # outside: the texture's unit arms
+    s4 = mixed_pair(H, W, D, seed=7, flat_frac=0.04)[0]
+    assert 0.03 < (s4 == s4.max()).mean() < 0.12
 
 
 def arm_stats(oracle, x0, x1, L1, tau1, ds=(0, 30, 60, 120)):
