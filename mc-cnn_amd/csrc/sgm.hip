@@ -343,7 +343,8 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 	// MODE 0 writes 0 + L_r (out:zero() then +=, main.lua:1014), its concurrent second direction L_r itself: x + (+0) and x + (-0)
 	const float zadd = ((DUAL && second) || MODE == 5) ? -0.0f : 0.0f;
 
-	auto process = [&](const StepData<VPL, NACC> &sd, int s) {
+	// keep != nullptr: the step's outputs go there instead of to memory (the horizontal sweeps' batched stores below)
+	auto process = [&](const StepData<VPL, NACC> &sd, int s, float *keep = nullptr) {
 		float val[VPL], o[VPL];
 		const int a0 = __builtin_amdgcn_readfirstlane((int)sd.a0);
 		const int amatch = a0 == 1 ? 3 : a0;
@@ -401,7 +402,12 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 			m = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(nm)));
 		} else
 		m = wave_min_q(nm);
-		store_step(o, s);
+		if (keep) {
+#pragma unroll
+			for (int j = 0; j < VPL; ++j) keep[j] = o[j];
+		} else {
+			store_step(o, s);
+		}
 	};
 
 	StepData<VPL, NACC> ring[U];
@@ -411,6 +417,18 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 	int g = 0;
 	// steady state: straight-line code, every slot is consumed and immediately refilled U steps ahead
 	// (refills past the end of the line re-read its last pixel; they are never consumed)
+	// Horizontal sweeps (round 5, MC_SGM_SB / MC_SGM_LB > 1): consecutive steps of a line are consecutive pixels, i.e. CONTIGUOUS memory -- the outputs of SB steps
+	// are stored together (SB runs back to back: one piece of SB x ds floats instead of SB pieces a step's recurrence apart) and the refills of LB slots requested together
+	// (A/B on one box, profiles/r05_ab_sgm_batched.txt, the horizontal launch at KITTI size: 772 us at 1 / 1, 761 at SB 4, 751 at LB 4, 746 at 4 / 4, 751 at 8 / 8; 1000 x 1500: 2 470 -> 2 462)
+#ifndef MC_SGM_SB
+#define MC_SGM_SB 4
+#endif
+#ifndef MC_SGM_LB
+#define MC_SGM_LB 4
+#endif
+	constexpr int SB = (DIRN <= 1 && !ARGMIN && U % MC_SGM_SB == 0) ? MC_SGM_SB : 1;
+	constexpr int LB = (DIRN <= 1 && U % MC_SGM_LB == 0) ? MC_SGM_LB : 1;
+	float obuf[SB][VPL];
 	for (; g + U <= nsteps; g += U) {
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
@@ -418,9 +436,22 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 			// keep each step's work behind its own s_waitcnt: without the barrier the machine scheduler hoists the
 			// recurrence-independent adds of ALL ring slots to the loop head, i.e. waits for every prefetch at once
 			__builtin_amdgcn_sched_barrier(0);
-			process(ring[u], s);
-			const int sn = s + U;
-			load_step(ring[u], sn < last ? sn : last);
+			if (SB > 1) {
+				process(ring[u], s, obuf[u % SB]);
+				if (u % SB == SB - 1) {
+#pragma unroll
+					for (int k = 0; k < SB; ++k) store_step(obuf[k], s - (SB - 1) + k);
+				}
+			} else {
+				process(ring[u], s);
+			}
+			if (u % LB == LB - 1) {
+#pragma unroll
+				for (int k = 0; k < LB; ++k) {
+					const int sn = s - (LB - 1) + k + U;
+					load_step(ring[u - (LB - 1) + k], sn < last ? sn : last);
+				}
+			}
 		}
 	}
 #pragma unroll
