@@ -34,7 +34,8 @@ def _p(t):
 
 
 def _scratch_for(device, need):
-    key = (device.index, need)
+    # one area per (device, size, stream): calls on different streams may run at the same time
+    key = (device.index, need, _stream())
     scratch = _scratch.get(key)
     if scratch is None:
         scratch = _scratch[key] = torch.empty(need, dtype=torch.uint8, device=device)

@@ -5,7 +5,7 @@
 mirrors `./main.lua kitti fast -a predict ...` (main.lua:10-32 flags, 1084-1105 action): loads the two images, converts
 RGB to luma, normalises each to zero mean / unit (unbiased) std on the host, uploads (2,1,H,W), runs the feature net
 (arch fast: l1 x [3x3 conv, pad 1, ReLU] with no ReLU after the last conv, then Normalize2 -- main.lua:727-746; the
-convolutions go through PyTorch-ROCm / MIOpen, everything after them through libmcadcensus.so), then the post-CNN
+convolutions are `mc_conv3x3`, a hand-written fp32-MFMA implicit GEMM of libmcadcensus.so, like everything after them), then the post-CNN
 pipeline in one `mc_predict` call, and writes `left.bin`, `right.bin` (1,D,H,W) and `disp.bin` (1,1,H,W), raw float32,
 with the reference's messages.  `-a time` is main.lua:1140-1167 (min of N runs on an uninitialised batch).
 
@@ -128,13 +128,19 @@ def load_fc(net_fname, dataset):
     return [(z["fw%d" % (i + 1)].astype(np.float32), z["fb%d" % (i + 1)].astype(np.float32)) for i in range(len(dims) - 1)]
 
 
+def device_layers(layers, device):
+    """[(w, b)] as float32 tensors on `device`: upload a net once, not once per call."""
+    import torch
+    return [tuple(t if isinstance(t, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).to(device) for t in wb)
+            for wb in layers]
+
+
 def features_slow(x_batch, layers):
     """forward_free(net_te, x_batch) for arch slow (main.lua:681-686): l1 x [3x3 conv, pad 1, ReLU]."""
-    import torch
     from . import adcensus
     h = x_batch.contiguous()
-    for w, b in layers:
-        h = adcensus.conv3x3(h, torch.from_numpy(w).to(h.device), torch.from_numpy(b).to(h.device), relu=True)
+    for w, b in device_layers(layers, h.device):
+        h = adcensus.conv3x3(h, w, b, relu=True)
     return h
 
 
@@ -155,8 +161,9 @@ def features_fast(x_batch, layers):
     import torch
     from . import adcensus
     h = x_batch.contiguous()
+    layers = device_layers(layers, h.device)
     for i, (w, b) in enumerate(layers):
-        h = adcensus.conv3x3(h, torch.from_numpy(w).to(h.device), torch.from_numpy(b).to(h.device), relu=i < len(layers) - 1)
+        h = adcensus.conv3x3(h, w, b, relu=i < len(layers) - 1)
     norm = torch.empty((h.shape[0], 1) + tuple(h.shape[2:]), dtype=torch.float32, device=h.device)
     out = torch.empty_like(h)
     adcensus.Normalize_forward(h, norm, out)   # Normalize2.lua:8-13 -> adcensus.cu:1310-1333
@@ -172,7 +179,7 @@ def main(argv=None):
     dev = torch.device("cuda", opt.gpu - 1)
     torch.cuda.set_device(dev)
     learned = arch in ("fast", "slow")
-    layers = load_net(opt.net_fname, dataset, arch) if learned else []
+    layers = device_layers(load_net(opt.net_fname, dataset, arch), dev) if learned else []   # resident: uploaded once
     fc_layers = load_fc(opt.net_fname, dataset) if arch == "slow" else None
     prm["border_n"] = len(layers)  # (1 + l1*(3-1) - 1) / 2, main.lua:382-391,923
 
