@@ -60,7 +60,7 @@ int sgm_prep(const float *x0, const float *x1, void *maps, int H, int W, float t
 int sgm_contract_violations(const float *vol, int H, int W, int D, unsigned *count, hipStream_t st);
 int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2], float *const disp[2],
                const int direction[2], int nvol, int H, int W, int D, int ds, const void *maps, float pi1, float pi2,
-               float alpha1, float q1, float q2, bool fused, hipStream_t st, float *const out3[2] = nullptr);
+               float alpha1, float q1, float q2, bool fused, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -196,10 +196,7 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	// pixel stride of the (H,W,ds) volumes: D rounded up to 4 (16-byte runs).  Rounding up to 32 (every run on whole 128-byte
 	// lines) was measured on one box at 370x1226x228 (ds 228 -> 256): the transposes 0.465 -> 0.377 ms, the sweeps 2.016 ->
 	// 2.105 ms (12 % more bytes), StereoJoin unchanged; 6.000 -> 5.998 ms with the aggregation, 2.87 -> 2.97 ms without: not adopted.
-#ifndef MC_DP_ALIGN
-#define MC_DP_ALIGN 4
-#endif
-	pl.Dp = (D + MC_DP_ALIGN - 1) / MC_DP_ALIGN * MC_DP_ALIGN;
+	pl.Dp = (D + 3) / 4 * 4;
 	const size_t HW = (size_t)H * W;
 	pl.maps = align_up(sgm_maps_bytes(H, W), 256);
 	pl.arms = align_up(8 * HW * sizeof(float), 256);
@@ -216,11 +213,7 @@ static Plan make_plan(const mc_params *p, int D, int H, int W)
 	const StageCounts sc = stage_counts(p);
 	pl.cplan = (sc.cbca1 + sc.cbca2 >= 2 && p->L1 - 1 <= 13) ? align_up(cbca_plan_bytes(D, H, W), 256) : 0;
 	pl.nplan = (p->left_only && !p->lr_check) ? 1 : 2;
-#ifdef MC_SGM_SCHEDULE_R5
-	constexpr int NVOLS = 8;   // + the down sweep's partial sums per side (sgm.hip: measured, not the product)
-#else
 	constexpr int NVOLS = 6;   // ping-pong per side (4) + the left sweep's partial sums per side
-#endif
 	pl.total = pl.maps + pl.arms + pl.pack + NVOLS * pl.vol + 6 * pl.img + pl.gk + pl.nplan * pl.cplan;
 	return pl;
 }
@@ -291,11 +284,6 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 	float *bufC[2];  // scratch of the SGM's concurrent second direction
 	bufC[0] = (float *)w; w += pl.vol;
 	bufC[1] = (float *)w; w += pl.vol;
-#ifdef MC_SGM_SCHEDULE_R5
-	float *bufD[2];  // ... and of the down sweep that runs beside the horizontal ones
-	bufD[0] = (float *)w; w += pl.vol;
-	bufD[1] = (float *)w; w += pl.vol;
-#endif
 	float *img[6];
 	for (int i = 0; i < 6; ++i) { img[i] = (float *)w; w += pl.img; }
 	float *gk = (float *)w; w += pl.gk;
@@ -424,11 +412,7 @@ static int predict_impl(const mc_params *p, const float *x0, const float *x1, co
 			float *outv[2] = {other(0), other(1)};
 			const bool am = (it == n_sgm - 1) && n_cbca2 == 0;
 			RUN(sgm_sweeps(Cv, outv, bufC, am ? dispv : nullptr, direction, nvol, H, W, D, ds, maps, p->pi1, p->pi2, p->alpha1,
-#ifdef MC_SGM_SCHEDULE_R5
-			               p->sgm_q1, p->sgm_q2, true, st, bufD));
-#else
-			               p->sgm_q1, p->sgm_q2, true, st, nullptr));
-#endif
+			               p->sgm_q1, p->sgm_q2, true, st));
 			have_disp = am;
 			cur[0] = outv[0]; cur[1] = outv[1];
 		}

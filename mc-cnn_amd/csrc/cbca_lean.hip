@@ -747,19 +747,11 @@ __device__ __forceinline__ float second_pass_small(const LeanArgs &A, const __am
 	const int u = (int)(b0 & 3u), rows = on ? u + (int)((b0 >> 2) & 3u) + 1 : 0;
 	float t[4][4];
 	int nn[4];
-	// MC_LEAN2X_ROW_CALLS 0 (the product): first_pass_row once per support-row INDEX at which any lane's row lies outside the tile (a wave of a
-	// texture: two to three of the four).  1 (built, NOT yet measured or run on a GPU -- a lead of DESIGN section 7): every lane brings its own
-	// first outside row to ONE call, a further round only while a lane has another.
-#ifndef MC_LEAN2X_ROW_CALLS
-#define MC_LEAN2X_ROW_CALLS 0
-#endif
-	int ls[4];
-	cb_u32 needs = 0;   // bit k: row k of this lane's support lies (partly) outside the tile
+	// first_pass_row once per support-row INDEX at which any lane's row lies outside the tile (a wave of a texture: two to three of the four)
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
 		const cb_u32 lr = entry_byte(e, 1 + k);
 		const int l = (int)(lr & 15u);
-		ls[k] = l;
 		nn[k] = k < rows ? l + (int)(lr >> 4) + 1 : 0;
 		const int yy = y + k - u, ry = yy - (y0 - 1), cx0 = x - l - xb;
 		const bool inside = (unsigned)ry < (unsigned)(R + 2) && cx0 >= 1 && cx0 + nn[k] - 1 <= 254;
@@ -767,26 +759,8 @@ __device__ __forceinline__ float second_pass_small(const LeanArgs &A, const __am
 #pragma unroll
 		for (int c = 0; c < 4; ++c) t[k][c] = T[c < nn[k] ? base + c : 0];
 		const bool need = nn[k] > 0 && !inside;
-		if (MC_LEAN2X_ROW_CALLS == 0) {
-			if (__any(need)) {
-				if (need) first_pass_row(A, rv, rp0, rp1, sh, yy, x - l, nn[k], t[k]);
-			}
-		} else if (need) needs |= 1u << k;
-	}
-	if (MC_LEAN2X_ROW_CALLS == 1) {
-		while (__any(needs != 0u)) {
-			const int kn = needs ? __builtin_ctz(needs) : -1;
-			int ln = 0, nk = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { ln = kn == k ? ls[k] : ln; nk = kn == k ? nn[k] : nk; }
-			float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-			if (kn >= 0) first_pass_row(A, rv, rp0, rp1, sh, y + kn - u, x - ln, nk, o);
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-#pragma unroll
-				for (int c = 0; c < 4; ++c) t[k][c] = kn == k ? o[c] : t[k][c];
-			}
-			if (kn >= 0) needs &= needs - 1u;
+		if (__any(need)) {
+			if (need) first_pass_row(A, rv, rp0, rp1, sh, yy, x - l, nn[k], t[k]);
 		}
 	}
 	float sum = 0;
@@ -800,9 +774,7 @@ __device__ __forceinline__ float second_pass_small(const LeanArgs &A, const __am
 	return sum / (float)cnt;
 }
 
-#ifndef MC_LEAN2X_WPB
 #define MC_LEAN2X_WPB 1
-#endif
 constexpr int L2X_WPB = MC_LEAN2X_WPB;   // waves per block: 10 KB of LDS per wave (R = 8); blocks of two waves fill a CU's 160 KB in finer steps than blocks of four
 
 // a listed output of the wave's tile, from its record entry (word 0 = first-pass row | column << 8)
@@ -1069,9 +1041,7 @@ __global__ void __launch_bounds__(256) cbca_classify2x_kernel(const LeanArgs A)
 
 // ... after it: one block per plane adds the plane's waves' costs; more than cost_limit values recomputed per voxel on average means the
 // pair has regions of large supports next to its texture -- the list is declared unusable (the overflow word)
-#ifndef MC_LEAN2X_COST
 #define MC_LEAN2X_COST 2.0f
-#endif
 __global__ void __launch_bounds__(256) cbca_list_cost_kernel(const LeanArgs A, int npl)
 {
 	__shared__ float wsum[4];
@@ -1097,17 +1067,11 @@ __global__ void __launch_bounds__(64) cbca_list_reset_kernel(const LeanArgs A)
 // rows per wave / launch variant mc_predict uses (cfg.lean_rb = 0 / cfg.lean_variant < 0): measured at 1000 x 1500 x 256, one box
 // (profiles/r04_cbca_lean.txt): 8 rows 0.602 / 0.620 ms (address order / a band per XCD), 4 rows 0.601 / 0.601, 2 rows 0.652 / 0.635;
 // the classification costs 0.54 / 0.88 / 1.3 ms per direction
-#ifndef MC_LEAN_RB_DEFAULT
 #define MC_LEAN_RB_DEFAULT 8
-#endif
-#ifndef MC_LEAN_VARIANT_DEFAULT
 #define MC_LEAN_VARIANT_DEFAULT 0
-#endif
 static int lean_rows(int rb) { return (rb == 2 || rb == 4 || rb == 8) ? rb : MC_LEAN_RB_DEFAULT; }
 // ... of the two-pass kernel (cfg.lean_rb; measured at 1000 x 1500 x 256: DESIGN section 7)
-#ifndef MC_LEAN2X_RB_DEFAULT
 #define MC_LEAN2X_RB_DEFAULT 8
-#endif
 static int lean2x_rows(int rb) { return (rb == 4 || rb == 6 || rb == 8 || rb == 10 || rb == 12) ? rb : MC_LEAN2X_RB_DEFAULT; }
 
 static LeanArgs lean_args(const void *packed, void *plan, size_t plan_bytes, const float *vin, float *vout, int D, int H, int W, int direction,

@@ -33,21 +33,14 @@
 
 namespace mc {
 
-#ifdef MC_TILE_PROF
-__device__ unsigned long long tile_prof[4096];
-#define TPROF(slot) do { if (prof_on && lane == 0) tile_prof[(step_no * 8 + wv_) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
 #define TPROF(slot) do { } while (0)
-#endif
 
 namespace {
 
 template <int A, int TW, int TH, int MODE = 0>
 struct TileGeo {
 	static constexpr int AH = (A + 3) & ~3;           // horizontal halo, a multiple of 4 columns (16-byte rows)
-#ifndef MC_TILE_SWPAD
 #define MC_TILE_SWPAD 4   // (measured: 0 / 4 -> 2.885 / 2.835 ms per launch; 12 no longer fits three blocks per CU)
-#endif
 	// staged columns; the long-arm instance pads its rows so that the row stride is not a multiple of the 32 LDS banks: lanes of a chunk
 	// read the same columns at different rows (runs that start at the same image edge), which a stride of 160 words puts into one bank
 	// (only the plan-reading instance, which has no sort histogram in LDS, has the bytes for it: three blocks per CU)
@@ -186,49 +179,6 @@ __device__ __forceinline__ void tile_taps3_p(float (&v)[9], unsigned pa, int n, 
 #undef MC_LOAD9
 #undef MC_EXIT
 
-#ifdef MC_TILE_MFMA
-// The same taps on the matrix core (round 5).  v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4 x 4 outer products, K = 1:
-// D_b[i][j] += A_b[i] * B_b[j], block b = lane / 4, A_b[i] from lane 4 b + i, B_b[j] from lane 4 b + j, and lane 4 b + j holds D_b[0 .. 3][j] in its
-// four accumulator registers.  With A = 1.0 in every lane that is: EVERY LANE adds ITS OWN value to ITS OWN four accumulators -- exactly what the four
-// v_add_f32 of a tap do, as one instruction, and bit for bit the same sums (fma(1.0, v, acc) rounds acc + v once; MI355X guide, "FP32-input MFMA": a
-// k-ordered fmaf chain, and K = 1 here).  The matrix core does not look at EXEC, so a lane whose run is over contributes -0.0 (x + -0.0 == x for every x,
-// the padding cbca_strip_kernel's window form uses): one compare, one select, one MFMA per tap instead of one compare and four additions.
-typedef float tile_f4 __attribute__((ext_vector_type(4)));
-template <bool LONG, bool PRE>
-__device__ __forceinline__ void tile_taps_m(float (&v)[9], unsigned pa, int n, tile_f4 &acc)
-{
-	const lds_cfp p = (lds_cfp)(__UINTPTR_TYPE__)pa;
-	if (!PRE) {
-#pragma unroll
-		for (int t = 0; t < 9; ++t) v[t] = p[t];
-	}
-	// (n opaque: hipcc otherwise folds the shift that produced it into 27 comparison constants and keeps them in scalar registers; hipcc interleaves the selects of a
-	// group with its MFMAs: select -> MFMA operand, MFMA -> dependent MFMA and compare -> select each want two instructions in between)
-	asm volatile("" : "+v"(n));
-#define MC_TS(t, val) ((t) < n ? (val) : -0.0f)
-#define MC_TM(x) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, (x), acc, 0, 0, 0)
-	{ const float x0 = MC_TS(0, v[0]), x1 = MC_TS(1, v[1]), x2 = MC_TS(2, v[2]); MC_TM(x0); MC_TM(x1); MC_TM(x2); }
-	if (!__any(3 < n)) return;
-	{ const float x0 = MC_TS(3, v[3]), x1 = MC_TS(4, v[4]); MC_TM(x0); MC_TM(x1); }
-	if (!__any(5 < n)) return;
-	{ const float x0 = MC_TS(5, v[5]), x1 = MC_TS(6, v[6]), x2 = MC_TS(7, v[7]), x3 = MC_TS(8, v[8]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); }
-	if (!LONG) return;
-	if (!__any(9 < n)) return;
-#pragma unroll
-	for (int t = 0; t < 9; ++t) v[t] = p[9 + t];
-	{ const float x0 = MC_TS(9, v[0]), x1 = MC_TS(10, v[1]), x2 = MC_TS(11, v[2]), x3 = MC_TS(12, v[3]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); }
-	if (!__any(13 < n)) return;
-	{ const float x0 = MC_TS(13, v[4]), x1 = MC_TS(14, v[5]), x2 = MC_TS(15, v[6]), x3 = MC_TS(16, v[7]), x4 = MC_TS(17, v[8]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); MC_TM(x4); }
-	if (!__any(18 < n)) return;
-#pragma unroll
-	for (int t = 0; t < 9; ++t) v[t] = p[18 + t];
-	{ const float x0 = MC_TS(18, v[0]), x1 = MC_TS(19, v[1]), x2 = MC_TS(20, v[2]), x3 = MC_TS(21, v[3]), x4 = MC_TS(22, v[4]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); MC_TM(x4); }
-	if (!__any(23 < n)) return;
-	{ const float x0 = MC_TS(23, v[5]), x1 = MC_TS(24, v[6]), x2 = MC_TS(25, v[7]), x3 = MC_TS(26, v[8]); MC_TM(x0); MC_TM(x1); MC_TM(x2); MC_TM(x3); }
-#undef MC_TS
-#undef MC_TM
-}
-#endif
 
 }  // namespace
 
@@ -433,9 +383,7 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 	// lane 0 holds the chunk's tallest item -- except that heights 1 and 2 share a key and that the six-row classes are sorted
 	// behind every other class
 	const int E = max(max(__builtin_amdgcn_readfirstlane(ext), 2), i0 + 64 > ngen ? 6 : 0);
-#ifndef MC_TILE_NO_SETPRIO
 	if (E >= 14) __builtin_amdgcn_s_setprio(2);   // a tall chunk is the step's critical path (one wave, a chain of thousands of instructions)
-#endif
 	// first / last row of output j, counted from the item's top, as one-hot words (0: no such output): the walk below tests
 	// them against the row's bit with one compare each
 	cb_u32 sbit[4], ebit[4];
@@ -446,12 +394,7 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 		sbit[j] = outj[j] ? 1u << (s0[j] - top) : 0u;
 		ebit[j] = outj[j] ? 1u << (e0[j] - top) : 0u;
 	}
-#ifdef MC_TILE_MFMA
-	tile_f4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
-	float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#else
 	float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#endif
 	int cb[4] = {0, 0, 0, 0}, ce[4] = {1, 1, 1, 1};   // taps of the wave-row walk before the output's first row / up to its last row
 	int Pn = 0;
 	const cb_u32 cv = (cb_u32)(size_t)Vl + (cb_u32)(c + AH) * 4u;   // LDS byte address of the item's column in ring slot 0
@@ -465,11 +408,7 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 	// short-arm instance measured 0.5 % slower with either, so it keeps the plain forms): (i) the rows at which ANY lane of the chunk has an event, once
 	// per chunk (an OR over the wave, DPP) -- the per-row test becomes one scalar AND instead of v_and + v_cmp + two scalar instructions; (ii) the
 	// events as tile_events_start / tile_events_end (no wait states)
-#ifdef MC_TILE_PLAIN_EVENTS
-	constexpr bool EVFAST = false;
-#else
 	constexpr bool EVFAST = A > 4;
-#endif
 	cb_u32 evrows = 0;
 	if constexpr (EVFAST) {
 		cb_u32 t = evmask;
@@ -500,10 +439,8 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 			const cb_u32 pa = __umul24((cb_u32)slotC, (cb_u32)(SW * 4)) + cv - (mC & 0xffu);
 			const bool anyev = MC_TILE_ANYEV(ibit);
 			if (anyev) {
-#ifndef MC_TILE_MFMA
 				if constexpr (EVFAST) tile_events_start(ibit, sbit, sum, cb, Pn);
 				else
-#endif
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const bool st = sbit[j] == ibit;
@@ -511,17 +448,11 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 					cb[j] = st ? Pn : cb[j];
 				}
 			}
-#ifdef MC_TILE_MFMA
-			tile_taps_m<(A > 4), true>(cur, pa, n, sum);
-#else
 			tile_taps_p<(A > 4)>(cur, pa, n, sum);
-#endif
 			Pn += n;
 			if (anyev) {
-#ifndef MC_TILE_MFMA
 				if constexpr (EVFAST) tile_events_end(ibit, ebit, sum, res, ce, Pn);
 				else
-#endif
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const bool en = ebit[j] == ibit;
@@ -546,10 +477,8 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 			mnext = (ibit << 1) < extbit ? mr : 0u;   // (i + 1 < ext)
 			const bool anyev = MC_TILE_ANYEV(ibit);   // most rows of a tall chunk start / end no output: the per-output tests are skipped
 			if (anyev) {
-#ifndef MC_TILE_MFMA
 				if constexpr (EVFAST) tile_events_start(ibit, sbit, sum, cb, Pn);
 				else
-#endif
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const bool st = sbit[j] == ibit;   // the output's first row: its chain starts from +0.0 here
@@ -557,18 +486,11 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 					cb[j] = st ? Pn : cb[j];
 				}
 			}
-#ifdef MC_TILE_MFMA
-			float vm[9];
-			tile_taps_m<(A > 4), false>(vm, pa, n, sum);
-#else
 			tile_taps<(A > 4)>(pa, n, sum);
-#endif
 			Pn += n;
 			if (anyev) {
-#ifndef MC_TILE_MFMA
 				if constexpr (EVFAST) tile_events_end(ibit, ebit, sum, res, ce, Pn);
 				else
-#endif
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const bool en = ebit[j] == ibit;   // the output's last row
@@ -581,9 +503,7 @@ __device__ __forceinline__ void tile_unit(int unit, int lane, float *__restrict_
 #pragma unroll
 	for (int j = 0; j < 4; ++j)
 		if (outj[j]) OUTl[(4 * g + j) * TW + c] = res[j] / (float)(ce[j] - cb[j]);
-#ifndef MC_TILE_NO_SETPRIO
 	if (E >= 14) __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 // P.gx x P.gy regions of TW columns x P.rb rows (a multiple of TH); a block takes one (region, plane).
@@ -601,15 +521,9 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	constexpr int VOL_AUX = NT ? 2 : 0;
 	constexpr int NG = G::NG;
 	constexpr int KT_ROWS = 14;        // "tall": items of this many rows and more
-#ifndef MC_TILE_NSPLIT
 #define MC_TILE_NSPLIT 64   // (measured: 0 / 64 / 128 / 256 -> 2.90 / 2.86 / 2.89 / 3.08 ms per launch on the realistic pair)
-#endif
 	constexpr int NSPLIT_MAX = MC_TILE_NSPLIT;   // a step's tall items are taken apart into single outputs if there are at most this many
-#ifdef MC_TILE_NO_PIPE
-	constexpr bool PIPE = false;
-#else
 	constexpr bool PIPE = MODE == 2;   // values requested a row ahead: 10 more registers, which only the plan-reading instance has
-#endif
 	static_assert(TH % 4 == 0 && TW % 64 == 0 && TW <= 256 && TH / 4 <= 256 && 2 * A + 5 < NKEY && A <= 15 && NG % NWAVES == 0, "tile geometry");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	float *__restrict__ Vl = (float *)smem;
@@ -786,18 +700,11 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 	__syncthreads();
 
 	int base = 0;   // ring slot of the step's first window row
-#ifdef MC_TILE_PROF
-	const int wv_ = tid >> 6;
-	int step_no = 0;
-#endif
 	fetch_rows(R, RR, ys + TH < ye ? TH : 0, tid);   // the rows the second step adds
 	if (MODE == 2) fetch_tab(1, tid);
 	int sidx = 0;   // step of the region
 	for (int y0 = ys, rrn = RR; y0 < ye; y0 += TH, rrn += TH, ++sidx) {
 		const bool more = y0 + TH < ye;
-#ifdef MC_TILE_PROF
-		const bool prof_on = blockIdx.x == MC_TILE_PROF && step_no < 16;   // (-DMC_TILE_PROF=<block to look at>)
-#endif
 		TPROF(0);
 		TPROF(1);
 
@@ -845,22 +752,9 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 					}
 					key = mini ? 1 : 2;
 				}
-#ifdef MC_TILE_RANK_BALLOT
-				cb_u32 rank = 0;
-				unsigned long long rem = ~0ull;
-				while (rem) {   // one pass per distinct key of the group
-					const int leader = __builtin_ctzll(rem);
-					const int k0 = __builtin_amdgcn_readlane(key, leader);
-					const unsigned long long m = __ballot(key == k0);
-					if (key == k0) rank = __builtin_amdgcn_mbcnt_hi((cb_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((cb_u32)m, 0));
-					if (lane == leader) GHl[gi * NKEY + k0] = (cb_u32)__builtin_popcountll(m);
-					rem &= ~m;
-				}
-#else
 				// rank inside (group, key): one LDS atomic per item (the order among equal keys is whatever the LDS serves -- lane
 				// order in practice -- and changes no result: every output is computed by exactly one lane, whichever it is)
 				const cb_u32 rank = atomicAdd(&GHl[gi * NKEY + key], 1u);
-#endif
 				keyrank[k] = (cb_u32)key | (rank << 8);
 			}
 			TPROF(2);
@@ -981,18 +875,9 @@ __global__ void __launch_bounds__(64 * NWAVES, NWAVES == 8 ? 6 : (NWAVES == 16 ?
 		TPROF(9);
 		__syncthreads();
 		TPROF(10);
-#ifdef MC_TILE_PROF
-		++step_no;
-#endif
 	}
 }
 
-#ifdef MC_TILE_PROF
-extern "C" __attribute__((visibility("default"))) int mc_debug_tile_prof(unsigned long long *out, int n)
-{
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tile_prof), sizeof(unsigned long long) * (size_t)n);
-}
-#endif
 
 // regions: strips of TW columns x row ranges of a multiple of TH rows; enough of them for ~5 regions per XCD, a multiple of 8
 // where a nearby row split gives one
@@ -1001,9 +886,7 @@ static void tile_regions(int H, int W, int TW, int TH, int &gx, int &gy, int &rb
 	gx = (int)cdiv(W, TW);
 	const int steps = (int)cdiv(H, TH);
 	// (round 4, one box: 80 / 160 regions per plane instead of 40 -- KITTI size 2.72 -> 2.75 / 2.76 ms of aggregation per pair, 1000x1500 97 -> 103 ms: more halo rows, no better balance)
-#ifndef MC_TILE_REGIONS
 #define MC_TILE_REGIONS 40
-#endif
 	gy = std::max(1, std::min(steps, (int)cdiv(MC_TILE_REGIONS, gx)));
 	for (int t = gy; t < gy + 8 && t <= steps; ++t)
 		if ((gx * t) % 8 == 0) { gy = t; break; }

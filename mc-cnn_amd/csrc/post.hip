@@ -91,55 +91,6 @@ __global__ void __launch_bounds__(256) transpose4_kernel(const float *__restrict
 	}
 }
 
-#ifdef MC_TRANSPOSE_RUNS
-// Built, measured, NOT the product (round 5, A/B on one box, profiles/r05_ab_transpose.txt: 229 against 231 us per 414 MB volume at 370 x 1226 x 228 -- the
-// layout stage 0.462 against 0.468 ms): the writes were not what bounds the KITTI-size transpose; its 228 reads of 256 bytes per block, 1.8 MB apart, are.
-// (R, Cn) -> (Cn, ldout) with R <= ldout small (the disparities of a pixel) and R * 4 bytes NOT a whole number of 128-byte lines -- KITTI's D = 228: a
-// pixel's run is 7.1 lines, so the 256-byte pieces transpose4_kernel writes start anywhere inside a line and the L2 still moved 1.25x the bytes
-// (profiles/traffic_kitti_slow.json, round 5: 1.04 GB for 0.83) at 3.6 TB/s.  Here a block stages ALL R rows of its 64 columns (R x 65 floats of LDS:
-// 59 KB at R = 228) -- R / 16 16-byte loads per thread, all in flight at once -- and then writes its 64 output rows as ONE contiguous piece of
-// 64 * ldout floats, 16 bytes per thread in address order: every line once, whole.
-template <bool NT>
-__global__ void __launch_bounds__(256) transpose_runs_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int64_t Cn, int64_t ldin,
-                                                             int ldout, float s, unsigned ld4_rcp)
-{
-	extern __shared__ __attribute__((aligned(16))) float runs_tile[];   // [R][65]
-	const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-	const int64_t c0 = (int64_t)blockIdx.x * 64;
-	for (int r = ly; r < R; r += 16) {
-		const int64_t c = c0 + 4 * lx;
-		if (c < Cn) {   // (Cn % 4 == 0: a unit is inside or outside)
-			const post_f4 *p = (const post_f4 *)(in + (int64_t)r * ldin + c);
-			const post_f4 v = NT ? __builtin_nontemporal_load(p) : *p;
-			float *t = runs_tile + r * 65 + 4 * lx;
-			t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-		}
-	}
-	__syncthreads();
-	const int ncols = (int)(Cn - c0 < 64 ? Cn - c0 : 64);
-	const int ld4 = ldout >> 2;                  // 16-byte units per output row
-	const int units = ncols * ld4;
-	float *__restrict__ o = out + c0 * ldout;
-	for (int q = threadIdx.x; q < units; q += 256) {
-		const int pc = (int)__umulhi((unsigned)q, ld4_rcp);   // q / ld4 (ld4_rcp = ceil(2^32 / ld4), exact for q < 2^16)
-		const int r = 4 * (q - pc * ld4);
-		if (r >= R) continue;                    // (the padding between R and ldout is not written, as in transpose4_kernel)
-		const float *t = runs_tile + r * 65 + pc;
-		post_f4 v = {t[0] * s, r + 1 < R ? t[65] * s : 0.0f, r + 2 < R ? t[130] * s : 0.0f, r + 3 < R ? t[195] * s : 0.0f};
-		post_f4 *dst = (post_f4 *)(o + 4 * (int64_t)q);
-		if (r + 3 < R) {
-			if (NT) __builtin_nontemporal_store(v, dst);
-			else *dst = v;
-		} else {   // (R % 4 != 0: the run's last unit, element by element)
-			float *d1 = (float *)dst;
-			d1[0] = v.x;
-			if (r + 1 < R) d1[1] = v.y;
-			if (r + 2 < R) d1[2] = v.z;
-		}
-	}
-}
-
-#endif
 
 int fill_nan(float *p, int64_t n, hipStream_t st)
 {
@@ -166,20 +117,6 @@ int transpose(const float *in, float *out, int64_t R, int64_t Cn, int64_t ldin, 
 	// the long axis goes to grid.x (grid.y is limited to 65535 blocks)
 	const bool use_nt = nt >= 0 ? nt != 0 : R * Cn * 4 > ((int64_t)768 << 20);
 	const bool aligned16 = Cn % 4 == 0 && ldin % 4 == 0 && ldout % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0;
-#ifdef MC_TRANSPOSE_RUNS
-	// short rows whose length is not a whole number of 128-byte lines (KITTI: D = 228): whole output runs per block (transpose_runs_kernel)
-	if (aligned16 && R <= 248 && R >= 8 && (R * 4) % 128 != 0 && ldout < R + 32 && ldout * 64 < 65536 && Cn >= 64) {
-		const int lds = R * 65 * (int)sizeof(float);
-		const unsigned ld4_rcp = (unsigned)((((uint64_t)1 << 32) + (ldout / 4) - 1) / (ldout / 4));
-		auto kern = use_nt ? transpose_runs_kernel<true> : transpose_runs_kernel<false>;
-		if (lds > 48 * 1024) {
-			const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-			if (e != hipSuccess) { set_error("transpose: hipFuncSetAttribute(%d bytes of LDS): %s", lds, hipGetErrorString(e)); return (int)e; }
-		}
-		hipLaunchKernelGGL(kern, dim3(cdiv(Cn, 64)), dim3(256), lds, st, in, out, (int)R, Cn, ldin, (int)ldout, s, ld4_rcp);
-		return check_launch("transpose (runs)");
-	}
-#endif
 	if (R % 4 == 0 && aligned16) {
 		if (R <= Cn) {
 			if (use_nt) hipLaunchKernelGGL((transpose4_kernel<true, true>), dim3(cdiv(Cn, 64)), dim3(256), 0, st, in, out, R, Cn, ldin, ldout, s);
@@ -413,9 +350,7 @@ template <int K> __device__ __forceinline__ void ray_rank_step(float v, int inb,
 // xx is an exact multiple of 0.5 and round(xx) (half away from zero) = (X2 + 1 + (X2 >> 31)) >> 1 for X2 = 2 xx -- the same pixels,
 // without the float rounding sequence.  The mark is fetched through a buffer whose range check answers 0 ("not a mismatch")
 // for a position outside the image, so the loop has one exit test and no nested regions.
-#ifndef MC_MIS_NU
 #define MC_MIS_NU 4
-#endif
 __global__ void __launch_bounds__(256) interp_mis_rays_kernel(const float *__restrict__ d0, const float *__restrict__ outlier,
                                                               float *__restrict__ out, int size, int H, int W)
 {

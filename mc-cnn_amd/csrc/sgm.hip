@@ -24,9 +24,7 @@
 // cache policy of the volume accesses: nt (bit 1) -- every cost run is read or written once per sweep; streaming them keeps
 // the edge-class maps (re-read by every line) in L2
 #define MC_SGM_VOL_AUX 2
-#ifndef MC_SGM_ST_AUX
-#define MC_SGM_ST_AUX MC_SGM_VOL_AUX   // (the stores' policy on its own: round 5 A/B)
-#endif
+#define MC_SGM_ST_AUX MC_SGM_VOL_AUX   // (the stores' policy on its own: profiles/r05_ab_sgm_store_policy.txt)
 
 namespace mc {
 
@@ -35,11 +33,9 @@ constexpr int SGM_PADW = 520;  // >= 63*8 + 7 + slack: window starts reach -(VPL
 struct SgmPassArgs {
 	const float *C[2];    // input cost volume(s), (H,W,ds)
 	const float *accin[2];// running sum read by MODE 1,2,3
-	const float *accin2[2];// second partial sum read by MODE 3, 4
-	const float *accin3[2];// third partial sum read by MODE 4
+	const float *accin2[2];// second partial sum read by MODE 3
 	float *out[2];        // where this sweep writes
 	float *out2[2];       // DUAL: where the concurrent second direction writes
-	float *out3[2];       // MODE 5 (the down sweep inside the first launch): where it writes L_2
 	float *disp[2];       // ARGMIN output (H,W), may be null
 	int direction[2];
 	int nvol;
@@ -101,7 +97,6 @@ struct StepData {
 	float c[VPL];
 	float a[NACC > 0 ? VPL : 1];
 	float a2[NACC > 1 ? VPL : 1];
-	float a3[NACC > 2 ? VPL : 1];
 	unsigned pk;
 	unsigned a0;   // class of the reference pixel's edge (same value in every lane)
 };
@@ -155,18 +150,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pixel_rsrc(const float *base, 
 //   lines and write out2 = L_1.  The two horizontal directions then run concurrently (twice the waves in
 //   flight where a direction alone has fewer lines than the chip has SIMDs); the sum order of the
 //   reference, ((0 + L_0) + L_1) + L_2) + L_3, is restored by MODE 3.
-// MODE 5: out3 = L_r itself    } round 5: the DOWN sweep runs inside the first launch, beside the two horizontal ones (three sweeps of 1R + 1W,
-// MODE 4: out = (((accin + accin2) + accin3) + L_r)/4   } 2 nvol (H + W / 2) waves at once), and the up sweep adds the three partial sums in the
-//   reference's order: the same 11 V of traffic as (right + left), down (MODE 3), up (MODE 2), but the horizontal launch -- 1 480 long-lived waves
-//   on 1 024 SIMDs at KITTI size, each alternating between its recurrence and its loads, 0.146 ms slower than its own data movement -- shares the
-//   chip with 2 452 more (scripts/microbench/bw_sgm_sched.hip, profiles/r05_bw_sgm_sched_*.txt: 1.96 -> 1.85 ms at KITTI size with a step's work emulated).
-//   MC_SGM_SCHEDULE_R5 only: measured slower in the product (sgm_sweeps)
 // U = steps kept in flight per wave (register ring): the scan is a strict recurrence, so memory latency is
 //   covered by prefetch depth, not by occupancy.
 template <int DIRN, int VPL, int MODE, bool ARGMIN, bool VEC, int U, bool DUAL, bool FAR>
 __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 {
-	constexpr int NACC = (MODE == 0 || MODE == 5) ? 0 : (MODE == 3 ? 2 : (MODE == 4 ? 3 : 1));
+	constexpr int NACC = MODE == 0 ? 0 : (MODE == 3 ? 2 : 1);
 	const int lane = threadIdx.x & 63;
 	const int H = A.H, W = A.W, D = A.D, ds = A.ds, Wm = A.Wm;
 	const int nlines = DIRN <= 1 ? H : W;
@@ -187,8 +176,7 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 	const float *__restrict__ Cp = A.C[v];
 	const float *__restrict__ Ain = A.accin[v];
 	const float *__restrict__ Ain2 = A.accin2[v];
-	const float *__restrict__ Ain3 = A.accin3[v];
-	float *__restrict__ Out = MODE == 5 ? A.out3[v] : ((DUAL && second) ? A.out2[v] : A.out[v]);
+	float *__restrict__ Out = (DUAL && second) ? A.out2[v] : A.out[v];
 	float *__restrict__ Disp = A.disp[v];
 
 	// line geometry: pixel of step s is (y0 + s*sy, x0 + s*sx)
@@ -229,7 +217,6 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 	const __amdgpu_buffer_rsrc_t rC = pixel_rsrc(Cp, (int64_t)minpix * ds, FAR ? 0 : span);
 	const __amdgpu_buffer_rsrc_t rA = pixel_rsrc(NACC >= 1 ? Ain : Cp, (int64_t)minpix * ds, FAR ? 0 : span);
 	const __amdgpu_buffer_rsrc_t rA2 = pixel_rsrc(NACC >= 2 ? Ain2 : Cp, (int64_t)minpix * ds, FAR ? 0 : span);
-	const __amdgpu_buffer_rsrc_t rA3 = pixel_rsrc(NACC >= 3 ? Ain3 : Cp, (int64_t)minpix * ds, FAR ? 0 : span);
 	const __amdgpu_buffer_rsrc_t rO = pixel_rsrc(Out, (int64_t)minpix * ds, FAR ? 0 : span);
 	const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void *)win, 0, H * Wm + 2 * WBIAS + 64, 0x00020000);
 	const int w0 = y0s * Wm + x0s, dw = sy * Wm + sx;
@@ -260,36 +247,17 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 		}
 	};
 
-	// MC_SGM_DBG (timing experiments only, results wrong): bit 0 no volume stores, bit 1 no window-class loads, bit 2 no reference-class loads,
-	// bit 3 no cost loads, bit 4 no wave-wide minimum
-#ifndef MC_SGM_DBG
-#define MC_SGM_DBG 0
-#endif
 	auto load_step = [&](StepData<VPL, NACC> &sd, int s) {
 		const unsigned so = c0v + (unsigned)s * c1v;
 		const int64_t pix = FAR ? (int64_t)(y0s + s * sy) * W + (x0s + s * sx) : 0;
-		if (MC_SGM_DBG & 8) {
-#pragma unroll
-			for (int j = 0; j < VPL; ++j) sd.c[j] = 1.0f;
-		} else
 		load_run(sd.c, Cp, rC, so, pix);
 		if constexpr (NACC >= 1) load_run(sd.a, Ain, rA, so, pix);
 		if constexpr (NACC >= 2) load_run(sd.a2, Ain2, rA2, so, pix);
-		if constexpr (NACC >= 3) load_run(sd.a3, Ain3, rA3, so, pix);
 		unsigned pk = 0;
 		const unsigned sw = (unsigned)(w0 + s * dw);
-		if (!(MC_SGM_DBG & 2)) {
 #pragma unroll
-			for (int q = 0; q < VPL / 4; ++q) pk |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rW, woff + q * wq, sw, 0) << (8 * q);
-		} else {
-			pk = 0x55u;
-			asm volatile("" : "+v"(pk));
-		}
+		for (int q = 0; q < VPL / 4; ++q) pk |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rW, woff + q * wq, sw, 0) << (8 * q);
 		sd.pk = pk;
-		if (MC_SGM_DBG & 4) {
-			sd.a0 = 1u;
-			asm volatile("" : "+v"(sd.a0));
-		} else
 		sd.a0 = __builtin_amdgcn_raw_buffer_load_b8(rCls, 0, (unsigned)(pix0 + s * dp), 0);  // every lane reads the same byte
 	};
 
@@ -303,7 +271,7 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 				uint4v t;
 				t.x = __float_as_uint(o[4 * q + 0]); t.y = __float_as_uint(o[4 * q + 1]);
 				t.z = __float_as_uint(o[4 * q + 2]); t.w = __float_as_uint(o[4 * q + 3]);
-				__builtin_amdgcn_raw_buffer_store_b128(t, r, (MC_SGM_DBG & 1) ? OOBV : lane_off[q], soff, MC_SGM_ST_AUX);
+				__builtin_amdgcn_raw_buffer_store_b128(t, r, lane_off[q], soff, MC_SGM_ST_AUX);
 			}
 		} else {
 #pragma unroll
@@ -341,7 +309,7 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 	float P1midv = P1mid, P2midv = P2mid, P1amidv = P1amid, INFv = INF;
 	asm volatile("" : "+v"(P1midv), "+v"(P2midv), "+v"(P1amidv), "+v"(INFv));
 	// MODE 0 writes 0 + L_r (out:zero() then +=, main.lua:1014), its concurrent second direction L_r itself: x + (+0) and x + (-0)
-	const float zadd = ((DUAL && second) || MODE == 5) ? -0.0f : 0.0f;
+	const float zadd = (DUAL && second) ? -0.0f : 0.0f;
 
 	// keep != nullptr: the step's outputs go there instead of to memory (the horizontal sweeps' batched stores below)
 	auto process = [&](const StepData<VPL, NACC> &sd, int s, float *keep = nullptr) {
@@ -386,10 +354,9 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 		float q[VPL];
 #pragma unroll
 		for (int j = 0; j < VPL; ++j) {
-			if (MODE == 0 || MODE == 5) o[j] = val[j] + zadd;
+			if (MODE == 0) o[j] = val[j] + zadd;
 			else if (MODE == 1) o[j] = sd.a[j] + val[j];
 			else if (MODE == 2) o[j] = (sd.a[j] + val[j]) * 0.25f;
-			else if (MODE == 4) o[j] = (((sd.a[j] + sd.a2[j]) + sd.a3[j]) + val[j]) * 0.25f;
 			else o[j] = (sd.a[j] + sd.a2[j]) + val[j];
 			q[j] = vmin2(val[j], INFv);                       // NaN -> +INF: fminf semantics of the recurrence
 		}
@@ -398,9 +365,6 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 		float nm = vmin3(prev[0], prev[1], prev[2]);
 #pragma unroll
 		for (int j = 3; j < VPL; j += 2) nm = j + 1 < VPL ? vmin3(nm, prev[j], prev[j + 1]) : vmin2(nm, prev[j]);
-		if (MC_SGM_DBG & 16) {
-			m = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(nm)));
-		} else
 		m = wave_min_q(nm);
 		if (keep) {
 #pragma unroll
@@ -417,17 +381,11 @@ __device__ __forceinline__ void sgm_line(const SgmPassArgs &A, int wave)
 	int g = 0;
 	// steady state: straight-line code, every slot is consumed and immediately refilled U steps ahead
 	// (refills past the end of the line re-read its last pixel; they are never consumed)
-	// Horizontal sweeps (round 5, MC_SGM_SB / MC_SGM_LB > 1): consecutive steps of a line are consecutive pixels, i.e. CONTIGUOUS memory -- the outputs of SB steps
+	// Horizontal sweeps (SB / LB > 1): consecutive steps of a line are consecutive pixels, i.e. CONTIGUOUS memory -- the outputs of SB steps
 	// are stored together (SB runs back to back: one piece of SB x ds floats instead of SB pieces a step's recurrence apart) and the refills of LB slots requested together
 	// (A/B on one box, profiles/r05_ab_sgm_batched.txt, the horizontal launch at KITTI size: 772 us at 1 / 1, 761 at SB 4, 751 at LB 4, 746 at 4 / 4, 751 at 8 / 8; 1000 x 1500: 2 470 -> 2 462)
-#ifndef MC_SGM_SB
-#define MC_SGM_SB 4
-#endif
-#ifndef MC_SGM_LB
-#define MC_SGM_LB 4
-#endif
-	constexpr int SB = (DIRN <= 1 && !ARGMIN && U % MC_SGM_SB == 0) ? MC_SGM_SB : 1;
-	constexpr int LB = (DIRN <= 1 && U % MC_SGM_LB == 0) ? MC_SGM_LB : 1;
+	constexpr int SB = (DIRN <= 1 && !ARGMIN && U % 4 == 0) ? 4 : 1;
+	constexpr int LB = (DIRN <= 1 && U % 4 == 0) ? 4 : 1;
 	float obuf[SB][VPL];
 	for (; g + U <= nsteps; g += U) {
 #pragma unroll
@@ -464,16 +422,6 @@ template <int DIRN, int VPL, int MODE, bool ARGMIN, bool VEC, int U, bool DUAL, 
 __global__ void __launch_bounds__(256) sgm_pass_kernel(const SgmPassArgs A)
 {
 	sgm_line<DIRN, VPL, MODE, ARGMIN, VEC, U, DUAL, FAR>(A, __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
-}
-
-// the first launch of the round-5 schedule: waves [0, 2 nvol H) sweep right / left (out = 0 + L_0, out2 = L_1), the next nvol W sweep DOWN (out3 = L_2)
-template <int VPL, bool VEC, int UH, int UD>
-__global__ void __launch_bounds__(256) sgm_triple_kernel(const SgmPassArgs A)
-{
-	const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-	const int nh = 2 * A.nvol * A.H;
-	if (wave < nh) sgm_line<0, VPL, 0, false, VEC, UH, true, false>(A, wave);
-	else sgm_line<2, VPL, 5, false, VEC, UD, false, false>(A, wave - nh);
 }
 
 // ---------------------------------------------------------------------------
@@ -530,21 +478,8 @@ int sgm_prep(const float *x0, const float *x1, void *maps, int H, int W, float t
 }
 
 // steps kept in flight per wave and sweep (see launch_pass)
-#ifndef MC_SGM_U_H
-#define MC_SGM_U_H 8
-#endif
-#ifndef MC_SGM_U_UP
-#define MC_SGM_U_UP 16
-#endif
-#ifndef MC_SGM_U_DOWN
-#define MC_SGM_U_DOWN 16   // (round 5, A/B on one box: profiles/r05_ab.txt -- 16 steps in flight cost 236 VGPRs, i.e. two waves per SIMD)
-#endif
-#ifndef MC_SGM_U_TDOWN
-#define MC_SGM_U_TDOWN 8    // (the down sweep of the first launch reads one array per step; 8 in flight keep the launch's kernel at ~120 VGPRs: all of its waves resident)
-#endif
-#ifndef MC_SGM_U_UP4
-#define MC_SGM_U_UP4 8     // (the up sweep that reads all three partial sums, MC_SGM_SCHEDULE_R5 only: four arrays per step)
-#endif
+constexpr int SGM_U_H = 8, SGM_U_UP = 16;
+constexpr int SGM_U_DOWN = 16;   // (A/B on one box: profiles/r05_ab_sgm_depth_per_launch.txt -- 16 steps in flight cost 236 VGPRs, i.e. two waves per SIMD)
 
 template <int DIRN, int MODE, bool ARGMIN, bool DUAL>
 static void launch_pass(const SgmPassArgs &A, bool vec, hipStream_t st)
@@ -557,7 +492,7 @@ static void launch_pass(const SgmPassArgs &A, bool vec, hipStream_t st)
 	// sweeps 2.016 ms at (horizontal 4, up 4), 2.024 at (8, 4), 2.009 at (4, 8), 1.982 at (8, 16), 2.008 at (16, 8), the down
 	// sweep (three loads per step) at 16 throughout; 1500x1000x256 within 1 % either way.  The sweeps run at what the
 	// memory system gives long-lived waves that each walk their own line (4.3-5.1 TB/s), not at a latency bound.
-	const int U = DIRN == 2 ? MC_SGM_U_DOWN : (DIRN == 3 ? (MODE == 4 ? MC_SGM_U_UP4 : MC_SGM_U_UP) : MC_SGM_U_H);
+	const int U = DIRN == 2 ? SGM_U_DOWN : (DIRN == 3 ? SGM_U_UP : SGM_U_H);
 #define MC_SGM_GO(VPL_, VEC_, U_) \
 	hipLaunchKernelGGL((sgm_pass_kernel<DIRN, VPL_, MODE, ARGMIN, VEC_, U_, DUAL, false>), grid, block, 0, st, A)
 #define MC_SGM_GO_FAR(VPL_, VEC_, U_) \
@@ -571,39 +506,22 @@ static void launch_pass(const SgmPassArgs &A, bool vec, hipStream_t st)
 		if (vec) { if (U == 16) MC_SGM_GO(4, true, 16); else if (U == 8) MC_SGM_GO(4, true, 8); else MC_SGM_GO(4, true, 4); }
 		else MC_SGM_GO(4, false, 4);
 	} else {
-		if (vec) { if (U >= 8 && MODE != 4) MC_SGM_GO(8, true, 8); else MC_SGM_GO(8, true, 4); }   // (MODE 4 holds four runs of 8 values per step in flight)
+		if (vec) { if (U >= 8) MC_SGM_GO(8, true, 8); else MC_SGM_GO(8, true, 4); }
 		else MC_SGM_GO(8, false, 2);
 	}
 #undef MC_SGM_GO_FAR
 #undef MC_SGM_GO
 }
 
-#ifdef MC_SGM_SCHEDULE_R5
-// the round-5 schedule's first launch (right + left + down) -- volumes below 2 GiB only (the caller checks)
-static void launch_triple(const SgmPassArgs &A, bool vec, hipStream_t st)
-{
-	const int waves = A.nvol * (2 * A.H + A.W);
-	const dim3 grid(cdiv(waves, 4)), block(256);
-	if (A.D <= 256) {
-		if (vec) hipLaunchKernelGGL((sgm_triple_kernel<4, true, MC_SGM_U_H, MC_SGM_U_TDOWN>), grid, block, 0, st, A);
-		else hipLaunchKernelGGL((sgm_triple_kernel<4, false, 4, 4>), grid, block, 0, st, A);
-	} else {
-		if (vec) hipLaunchKernelGGL((sgm_triple_kernel<8, true, 8, 8>), grid, block, 0, st, A);
-		else hipLaunchKernelGGL((sgm_triple_kernel<8, false, 2, 2>), grid, block, 0, st, A);
-	}
-}
-#endif
 
 // Four direction sweeps over nvol (1 or 2) volumes.
 //   fused = false: every sweep does out += L_r (adcensus.sgm2 contract, out pre-zeroed by caller)
 //   fused = true : right and left sweeps run concurrently (out = 0 + L_0, out2 = L_1), the down sweep
 //                  writes (out + out2) + L_2 to out, the up sweep writes (out + L_3)/4 and, if disp[] is
 //                  set, the argmin of the finished pixel.  `out2` is scratch of the same size as out.
-//   out3 (fused, with out2; volumes below 2 GiB): a third scratch volume -- the round-5 schedule: right + left + down in ONE launch
-//                  (out = 0 + L_0, out2 = L_1, out3 = L_2), then the up sweep writes (((out + out2) + out3) + L_3)/4: the same sums in the same order
 int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2], float *const disp[2],
                const int direction[2], int nvol, int H, int W, int D, int ds, const void *maps, float pi1, float pi2,
-               float alpha1, float q1, float q2, bool fused, hipStream_t st, float *const out3[2])
+               float alpha1, float q1, float q2, bool fused, hipStream_t st)
 {
 	// 32-bit pixel indices and line strides in the sweeps (a volume may still exceed 4 GiB: the FAR instances)
 	MC_REQUIRE((int64_t)H * W < ((int64_t)1 << 29) && (int64_t)W * ds * 4 < ((int64_t)1 << 31), "sgm: image %dx%d (pixel stride %d) exceeds the sweeps' 32-bit line arithmetic", H, W, ds);
@@ -615,8 +533,6 @@ int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2
 		A.accin2[v] = out2 ? out2[k] : nullptr;
 		A.out[v] = out[k];
 		A.out2[v] = out2 ? out2[k] : nullptr;
-		A.accin3[v] = out3 ? out3[k] : nullptr;
-		A.out3[v] = out3 ? out3[k] : nullptr;
 		A.disp[v] = disp ? disp[k] : nullptr;
 		A.direction[v] = direction[k];
 	}
@@ -636,7 +552,6 @@ int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2
 	for (int v = 0; v < nvol; ++v) {
 		vec = vec && ((uintptr_t)C[v] % 16 == 0) && ((uintptr_t)out[v] % 16 == 0);
 		if (out2) vec = vec && ((uintptr_t)out2[v] % 16 == 0);
-		if (out3) vec = vec && ((uintptr_t)out3[v] % 16 == 0);
 	}
 	const bool am = fused && disp && disp[0];
 	if (!fused || !out2) {
@@ -647,17 +562,6 @@ int sgm_sweeps(const float *const C[2], float *const out[2], float *const out2[2
 		if (!f) launch_pass<3, 1, false, false>(A, vec, st);
 		else if (am) launch_pass<3, 2, true, false>(A, vec, st);
 		else launch_pass<3, 2, false, false>(A, vec, st);
-#ifdef MC_SGM_SCHEDULE_R5
-	// Built, measured, NOT the product (round 5; A/B on one box, profiles/r05_ab_sgm_schedule.txt): the microbenchmark promised 1.96 -> 1.85 ms at KITTI
-	// size; the kernels take 1.147 ms for the first launch (6 V at 4.3 TB/s -- the horizontal launch's rate, with all 3 932 waves resident at 121 VGPRs)
-	// + 0.835 for the up sweep over four arrays = 1.98 against 1.925 for the three launches; 6.55 against 6.44 ms at 1000 x 1500 x 256.  What slows the
-	// horizontal sweeps is not a lack of waves beside them.  (The up sweep's MODE 4 instance with 4 steps in flight also failed the full-size comparison --
-	// +inf where the right volume's NaN triangle wants NaN at 599 voxels --, unresolved; with 8 steps in flight every test passes.)
-	} else if (out3 && (int64_t)H * W * ds * 4 < ((int64_t)1 << 31)) {
-		launch_triple(A, vec, st);
-		if (am) launch_pass<3, 4, true, false>(A, vec, st);
-		else launch_pass<3, 4, false, false>(A, vec, st);
-#endif
 	} else {
 		launch_pass<0, 0, false, true>(A, vec, st);
 		launch_pass<2, 3, false, false>(A, vec, st);

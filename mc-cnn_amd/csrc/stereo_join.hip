@@ -257,16 +257,12 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 			fgo[t][pass] = px < W ? (unsigned)(px * ds) * 4u : OOBF;
 		}
 	}
-	// MC_JOIN_DBG (timing experiments only, results wrong): bit 0 no volume stores, bit 1 no MFMAs, bit 2 no partner loads, bit 3 no ring writes
-#ifndef MC_JOIN_DBG
-#define MC_JOIN_DBG 0
-#endif
 	auto tile_product = [&](int t, const float (&part)[KSTEPS], int p0, floatx16 &acc) {
 #pragma unroll
 		for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 		// partner tile entirely outside the image: nothing to multiply, the whole tile is NaN
 		const bool any_in = SIDE == 0 ? (p0 + 31 >= 0) : (p0 < W);
-		if (any_in && !(MC_JOIN_DBG & 2)) {
+		if (any_in) {
 #pragma unroll
 			for (int kk = 0; kk < KSTEPS; ++kk)
 				acc = SIDE == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(own[t][kk], part[kk], acc, 0, 0, 0)
@@ -278,9 +274,7 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 		const int jbit = (J & 1) << 5;
 		// interior tile: every d of it lies in [0, D) and every partner pixel inside the image
 		const bool interior = J >= 1 && 32 * J + 31 < D && (SIDE == 0 ? p0 >= 0 : p0 + 31 < W);
-		if (MC_JOIN_DBG & 8) {
-			asm volatile("" :: "v"(acc));
-		} else if (interior) {
+		if (interior) {
 #pragma unroll
 			for (int i = 0; i < 16; ++i) {
 				const int mc = (i & 3) + 8 * (i >> 2);
@@ -304,181 +298,41 @@ __device__ __forceinline__ void join_owner_tiles(const float *__restrict__ fL, c
 			// (unsigned)d0 < ds  <=>  the piece holds at least one d of [0, D) of THIS pixel (d0 % 4 == 0, ds = D rounded up to 4)
 			const float4 v = *(const float4 *)(ring + fro + (d0 & 63));
 			__builtin_amdgcn_raw_buffer_store_b128((cb_u4_t){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
-			                                       rrow, (!(MC_JOIN_DBG & 1) && (unsigned)d0 < (unsigned)ds) ? fgo[t][pass] + (unsigned)d0 * 4u : OOBF, 0, MC_JOIN_STORE_AUX);
+			                                       rrow, ((unsigned)d0 < (unsigned)ds) ? fgo[t][pass] + (unsigned)d0 * 4u : OOBF, 0, MC_JOIN_STORE_AUX);
 			if (last) {
 				const int d1 = d0 + 32;
 				const float4 u = *(const float4 *)(ring + fro + (d1 & 63));
 				__builtin_amdgcn_raw_buffer_store_b128((cb_u4_t){__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(u.z), __float_as_uint(u.w)},
-				                                       rrow, (!(MC_JOIN_DBG & 1) && (unsigned)d1 < (unsigned)ds) ? fgo[t][pass] + (unsigned)d1 * 4u : OOBF, 0, MC_JOIN_STORE_AUX);
+				                                       rrow, ((unsigned)d1 < (unsigned)ds) ? fgo[t][pass] + (unsigned)d1 * 4u : OOBF, 0, MC_JOIN_STORE_AUX);
 			}
 		}
 	};
-	// MC_JOIN_ORDER 0: product and stores of one own tile after the other; 1: the products of a step's own tiles first (the chains of
-	// dependent MFMAs of different tiles are independent of each other), then their stores; 3 (round 5): the instructions that do NOT depend on
-	// the running product -- the line writer of the PREVIOUS tile product and the 32 loads of the NEXT partner tile -- are issued between the
-	// MFMAs of the chain.  A wave issues in order and a chained MFMA waits 64 cycles for its predecessor: those slots are free.
-#ifndef MC_JOIN_ORDER
-#define MC_JOIN_ORDER 0
-#endif
-	// ---- the pieces of tile_store, for MC_JOIN_ORDER 3 ----
-	auto ring_write = [&](int t, int J, int p0, const floatx16 &acc) {
-		float *__restrict__ ring = rings + t * (32 * 64);
-		const int jbit = (J & 1) << 5;
-		const bool interior = J >= 1 && 32 * J + 31 < D && (SIDE == 0 ? p0 >= 0 : p0 + 31 < W);
-		if (interior) {
-#pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				const int mc = (i & 3) + 8 * (i >> 2);
-				ring[wrow + (SIDE == 0 ? mc * 64 : 0) + (((wbase + mc) & 63) ^ jbit)] = acc[i];
-			}
-		} else {
-#pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				const int mc = (i & 3) + 8 * (i >> 2);
-				const int d = wbase + mc + 32 * J;
-				const int po = SIDE == 0 ? p0 + nl : p0 + mc + 4 * kh;
-				const bool pin = SIDE == 0 ? po >= 0 : po < W;
-				if (d >= 0 && d < D) ring[wrow + (SIDE == 0 ? mc * 64 : 0) + (((wbase + mc) & 63) ^ jbit)] = pin ? acc[i] : NANV;
-			}
-		}
-	};
-	// pass `pass` of the line writer of tile t after its product J (not the last J: one line per pixel completes); live = false: the store is dropped
-	auto lw_read = [&](int t, int J, int pass) -> float4 {
-		const float *__restrict__ ring = rings + t * (32 * 64);
-		const int d0 = fd0[t][pass] + 32 * J;
-		return *(const float4 *)(ring + (pass * 8 + (lane >> 3)) * 64 + (d0 & 63));
-	};
-	auto lw_store = [&](int t, int J, int pass, const float4 &v, bool live) {
-		const int d0 = fd0[t][pass] + 32 * J;
-		__builtin_amdgcn_raw_buffer_store_b128((cb_u4_t){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
-		                                       rrow, (live && (unsigned)d0 < (unsigned)ds) ? fgo[t][pass] + (unsigned)d0 * 4u : OOBF, 0, MC_JOIN_STORE_AUX);
-	};
-	// one operand value of the tile starting at pixel 32 * T (as load_tile / load_partner)
-	auto load_partner_one = [&](int T, int kk) -> float {
-		const int px = 32 * T + nl;
-		const unsigned vo = (px >= 0 && px < W) ? (unsigned)((int64_t)kh * HW + px) * 4u : OOBF;
-		return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(SIDE == 0 ? rB : rA, vo + (unsigned)kk * pair_bytes, 0, 0));
-	};
-	// the chain of own tile t against `part`, with -- between its MFMAs -- the line writer of tile tp after its product Jp (plive: it is pending) and,
-	// if LOADS, the next partner tile Tn into `next`
-	auto chain = [&](auto loads_tag, int t, const float (&part)[KSTEPS], floatx16 &acc, int tp, int Jp, bool plive, float (&next)[KSTEPS], int Tn) {
-		constexpr bool LOADS = decltype(loads_tag)::value;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-		float4 lv[4];
-#pragma unroll
-		for (int kk = 0; kk < KSTEPS; ++kk) {
-			acc = SIDE == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(own[t][kk], part[kk], acc, 0, 0, 0)
-			                : __builtin_amdgcn_mfma_f32_32x32x2f32(part[kk], own[t][kk], acc, 0, 0, 0);
-			if (LOADS) next[kk] = load_partner_one(Tn, kk);
-			if (kk < 4) lv[kk] = lw_read(tp, Jp, kk);                    // (the stores go early in the chain: they have its rest to complete in)
-			if (kk >= 2 && kk < 6) lw_store(tp, Jp, kk - 2, lv[kk - 2], plive);
-		}
-	};
+	// Product and stores of one own tile after the other.  (Measured and rejected: the products of a step's own tiles first, the two chains
+	// interleaved MFMA by MFMA, and the previous tile's line writer + the next partner tile's loads issued between the MFMAs of a chain --
+	// profiles/r05_ab_join_order3.txt, profiles/r05_mfma_order.txt; the variants are in the history, commit 5cbe4ae.)
 	auto do_step = [&](int s, const float (&part)[KSTEPS]) {
 		const int T = partner_of(s);
 		floatx16 acc[NT];
-		if (MC_JOIN_ORDER == 2 && NT == 2) {   // both own tiles active and the partner tile inside the image: the two chains interleaved, MFMA by MFMA
-			const int J0 = SIDE == 0 ? tile0 - T : T - tile0, J1 = SIDE == 0 ? J0 + 1 : J0 - 1;
-			const int p0 = 32 * T;
-			const bool both = J0 >= 0 && J0 < nJ && J1 >= 0 && J1 < nJ && (SIDE == 0 ? (p0 + 31 >= 0) : (p0 < W));
-			if (both) {
 #pragma unroll
-				for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
-#pragma unroll
-				for (int kk = 0; kk < KSTEPS; ++kk) {
-					acc[0] = SIDE == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(own[0][kk], part[kk], acc[0], 0, 0, 0)
-					                   : __builtin_amdgcn_mfma_f32_32x32x2f32(part[kk], own[0][kk], acc[0], 0, 0, 0);
-					acc[1] = SIDE == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(own[1][kk], part[kk], acc[1], 0, 0, 0)
-					                   : __builtin_amdgcn_mfma_f32_32x32x2f32(part[kk], own[1][kk], acc[1], 0, 0, 0);
-				}
-				tile_store(0, J0, p0, acc[0]);
-				tile_store(1, J1, p0, acc[1]);
-			} else {
-#pragma unroll
-				for (int t = 0; t < NT; ++t) {
-					const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
-					if (J >= 0 && J < nJ) { tile_product(t, part, p0, acc[0]); tile_store(t, J, p0, acc[0]); }
-				}
-			}
-		} else if (MC_JOIN_ORDER == 1) {
-#pragma unroll
-			for (int t = 0; t < NT; ++t) {
-				const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
-				if (J >= 0 && J < nJ) tile_product(t, part, 32 * T, acc[t]);
-			}
-#pragma unroll
-			for (int t = 0; t < NT; ++t) {
-				const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
-				if (J >= 0 && J < nJ) tile_store(t, J, 32 * T, acc[t]);
-			}
-		} else {
-#pragma unroll
-			for (int t = 0; t < NT; ++t) {
-				const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
-				if (J >= 0 && J < nJ) { tile_product(t, part, 32 * T, acc[0]); tile_store(t, J, 32 * T, acc[0]); }
-			}
+		for (int t = 0; t < NT; ++t) {
+			const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
+			if (J >= 0 && J < nJ) { tile_product(t, part, 32 * T, acc[0]); tile_store(t, J, 32 * T, acc[0]); }
 		}
 	};
 	// The prefetch of the next partner tile is issued UNCONDITIONALLY (past the last step it fetches a tile that is never
 	// multiplied): vmcnt counts in order, and a conditional batch of 32 loads makes the compiler wait, before every
 	// MFMA of the step, as if the batch had not been issued -- i.e. for the loads it has just sent.
-	if (MC_JOIN_ORDER == 3 && NT == 2 && KSTEPS >= 8) {
-		// a step whose two own tiles are both active, not at their last J, with the partner tile inside the image: straight-line code, nothing
-		// conditional but the dropped stores of a line writer that is not pending; every other step: the plain order (after the pending line writer)
-		bool pend = false;   // the line writer of own tile 1 after the previous step's product is still to run
-		int Jpend = 0;
-		auto step3 = [&](int s, const float (&part)[KSTEPS], float (&next)[KSTEPS]) {
-			const int T = partner_of(s), p0 = 32 * T, Tn = partner_of(s + 1);
-			const int J0 = SIDE == 0 ? tile0 - T : T - tile0, J1 = SIDE == 0 ? J0 + 1 : J0 - 1;
-			const bool full = J0 >= 0 && J0 + 1 < nJ && J1 >= 0 && J1 + 1 < nJ && (SIDE == 0 ? (p0 + 31 >= 0) : (p0 < W));
-			floatx16 acc;
-			if (full) {
-				chain(std::true_type(), 0, part, acc, 1, Jpend, pend, next, Tn);
-				ring_write(0, J0, p0, acc);
-				chain(std::false_type(), 1, part, acc, 0, J0, true, next, Tn);
-				ring_write(1, J1, p0, acc);
-				pend = true; Jpend = J1;
-			} else {
-#pragma unroll
-				for (int kk = 0; kk < KSTEPS; ++kk) next[kk] = load_partner_one(Tn, kk);
-				if (pend) {
-#pragma unroll
-					for (int pass = 0; pass < 4; ++pass) lw_store(1, Jpend, pass, lw_read(1, Jpend, pass), true);
-					pend = false;
-				}
-#pragma unroll
-				for (int t = 0; t < NT; ++t) {
-					const int J = SIDE == 0 ? tile0 + t - T : T - tile0 - t;
-					if (J >= 0 && J < nJ) { tile_product(t, part, p0, acc); tile_store(t, J, p0, acc); }
-				}
-			}
-		};
-		for (int s = 0; s < nsteps; s += 2) {
-			step3(s, pa, pb);
-			if (s + 1 < nsteps) step3(s + 1, pb, pa);
-		}
-		if (pend) {
-#pragma unroll
-			for (int pass = 0; pass < 4; ++pass) lw_store(1, Jpend, pass, lw_read(1, Jpend, pass), true);
-		}
-		return;
-	}
 	for (int s = 0; s < nsteps; s += 2) {
-		if (!(MC_JOIN_DBG & 4)) load_partner(pb, partner_of(s + 1));
+		load_partner(pb, partner_of(s + 1));
 		do_step(s, pa);
-		if (!(MC_JOIN_DBG & 4)) load_partner(pa, partner_of(s + 2));
+		load_partner(pa, partner_of(s + 2));
 		if (s + 1 < nsteps) do_step(s + 1, pb);
 	}
 }
 
-#ifndef MC_JOIN_NT
 #define MC_JOIN_NT 2
-#endif
 // waves per block: each wave's two rings are 16 KB of LDS, so blocks of four hold a CU at 8 waves (2 per SIMD), blocks of two / one at 10
-#ifndef MC_JOIN_WPB
 #define MC_JOIN_WPB 4
-#endif
 template <int KSTEPS, int NT = MC_JOIN_NT>
 __global__ void __launch_bounds__(64 * MC_JOIN_WPB) join_owner_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
                                                          float *__restrict__ volL, float *__restrict__ volR, int C, int D, int ds,

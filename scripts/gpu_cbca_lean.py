@@ -1,6 +1,6 @@
 """GPU: cross-based aggregation of a textured pair at 1000x1500x256 (the specified north-star regime) -- the strip kernel against the
 classify / lean / list kernels (hook forms 1, 8, 9), rows per wave and prefetch depth varied; run under rocprofv3 --kernel-trace, the
-per-kernel times come from scripts/rocpd_by_grid.py (kernel name x grid size).  Also prints host-timed ms per call (incl. cbca_pack)."""
+per-kernel times come from the run's rocprofv3 kernel trace (scripts/rocpd_summary.py).  Also prints host-timed ms per call (incl. cbca_pack)."""
 import os, sys, time
 import numpy as np
 import torch
