@@ -8,27 +8,64 @@
 
 namespace mc {
 
-// ---- v1: (D,H,W) outputs, one thread per (d,y,x), x fastest -------------------------------------
-// Reads of L and R and both stores are coalesced along x.  Only x-d >= 0 voxels are written
-// (the reference leaves the rest to the caller's NaN fill, main.lua:946).
+// ---- (D,H,W) outputs, the reference's layout (mc_stereo_join: what an unchanged main.lua calls) ---------------------
+// A block owns 64 pixels x 32 disparities of one image row: the two feature rows it needs -- L[c][x0 .. x0+63] and
+// R[c][x0-d0-31 .. x0-d0+63] -- are staged through LDS 16 channels at a time, a thread keeps the sums of 8 consecutive
+// disparities of one pixel (one value of L per channel against 8 of R), and both stores run along x.  Only x-d >= 0 voxels
+// are written (the reference leaves the rest to the caller's NaN fill, main.lua:946).  The chain is the reference's:
+// sum = fma(-L, R, sum), c ascending.  (Round 6: the one-thread-per-voxel form this replaces re-read every feature value
+// 32 times from L2 and took 7.2 ms of the op-by-op route's 10.3 ms per KITTI pair, profiles/r06_ops_route.txt.)
+constexpr int JD_PX = 64, JD_D = 32, JD_CK = 16, JD_RW = JD_PX + JD_D;   // 96 staged R columns (95 used)
+
 __global__ void __launch_bounds__(256) join_dhw_kernel(const float *__restrict__ fL, const float *__restrict__ fR,
                                                        float *__restrict__ volL, float *__restrict__ volR, int C, int D, int H, int W)
 {
-	const int x = blockIdx.x * 256 + threadIdx.x;
-	const int y = blockIdx.y;
-	const int d = blockIdx.z;
-	if (x >= W || x - d < 0) return;
+	__shared__ float Ls[JD_CK][JD_PX];
+	__shared__ float Rs[JD_CK][JD_RW];
+	const int tid = threadIdx.x, xi = tid & 63, dg = tid >> 6;
+	const int x0 = blockIdx.x * JD_PX, y = blockIdx.y, d0 = blockIdx.z * JD_D;
 	const int64_t HW = (int64_t)H * W;
-	const int64_t id = (int64_t)y * W + x;
-	float sum = 0;
-	for (int c = 0; c < C; ++c) sum = fmaf(-fL[c * HW + id], fR[c * HW + id - d], sum);
-	volL[d * HW + id] = sum;
-	volR[d * HW + id - d] = sum;
+	const float *__restrict__ rowL = fL + (int64_t)y * W;
+	const float *__restrict__ rowR = fR + (int64_t)y * W;
+	const int r0 = x0 - d0 - (JD_D - 1);             // image column of Rs[.][0]
+	float sum[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) sum[k] = 0.0f;
+	for (int c0 = 0; c0 < C; c0 += JD_CK) {
+		__syncthreads();
+		for (int e = tid; e < JD_CK * JD_PX; e += 256) {
+			const int c = e / JD_PX, i = e % JD_PX;
+			Ls[c][i] = (c0 + c < C && x0 + i < W) ? rowL[(int64_t)(c0 + c) * HW + x0 + i] : 0.0f;
+		}
+		for (int e = tid; e < JD_CK * JD_RW; e += 256) {
+			const int c = e / JD_RW, j = e % JD_RW;
+			const int xr = r0 + j;
+			Rs[c][j] = (c0 + c < C && xr >= 0 && xr < W) ? rowR[(int64_t)(c0 + c) * HW + xr] : 0.0f;
+		}
+		__syncthreads();
+		const int nc = min(JD_CK, C - c0);
+		for (int c = 0; c < nc; ++c) {
+			const float l = -Ls[c][xi];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) sum[k] = fmaf(l, Rs[c][xi + (JD_D - 1) - (dg * 8 + k)], sum[k]);   // R[x - d], d = d0 + 8 dg + k
+		}
+	}
+	const int x = x0 + xi;
+	if (x >= W) return;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const int d = d0 + dg * 8 + k;
+		if (d < D && x - d >= 0) {
+			const int64_t id = (int64_t)d * HW + (int64_t)y * W + x;
+			volL[id] = sum[k];
+			volR[id - d] = sum[k];
+		}
+	}
 }
 
 int stereo_join_dhw(const float *fL, const float *fR, float *volL, float *volR, int C, int D, int H, int W, hipStream_t st)
 {
-	hipLaunchKernelGGL(join_dhw_kernel, dim3(cdiv(W, 256), H, D), dim3(256), 0, st, fL, fR, volL, volR, C, D, H, W);
+	hipLaunchKernelGGL(join_dhw_kernel, dim3(cdiv(W, JD_PX), H, cdiv(D, JD_D)), dim3(256), 0, st, fL, fR, volL, volR, C, D, H, W);
 	return check_launch("stereo_join");
 }
 
