@@ -66,7 +66,11 @@ enum { CR_TILE4 = 0,          // every arm <= 4 (L1 <= 5): tile kernel, short-ar
 // head of the pair's plan area when the route is CR_STRIP (cbca_lean.hip): the list of outputs whose support is not the minimal 3 x 3
 enum { LH_COUNT = 0, LH_OVERFLOW = 1, LH_D = 2, LH_H = 3, LH_W = 4, LH_DIR = 5, LH_MAGIC = 6, LH_RB = 7, LH_WORDS = 64 };   // (wave table from word LH_WORDS on, then the slots)
 constexpr uint32_t LH_MAGIC_VALUE = 0x4c495354u;
-// written by cbca_classify_kernel for exactly this problem and wave geometry (rb rows per wave), and complete
+// written by cbca_classify_kernel for exactly this problem and wave geometry (rb rows per wave), and complete.
+// INVARIANT every caller keeps: the answer means something only together with `route == CR_STRIP` for the CURRENT pair -- the head is reset
+// (cbca_list_reset_kernel) and rewritten only when the pair takes that route, so a cached workspace may still hold a valid-looking head from an
+// EARLIER pair of the same shape whenever the current one takes a tile route.  A consumer that trusted list_valid alone would read another
+// image's records.
 __device__ __forceinline__ bool list_valid(const uint32_t *__restrict__ hdr, int D, int H, int W, int direction, int rb)
 {
 	return hdr[LH_MAGIC] == LH_MAGIC_VALUE && hdr[LH_D] == (uint32_t)D && hdr[LH_H] == (uint32_t)H && hdr[LH_W] == (uint32_t)W &&

@@ -224,11 +224,13 @@ __device__ __forceinline__ cb_u32 tile_item_rows(const unsigned char *__restrict
 // The first- / last-row events of a walk row (round 5): four compares into four scalar mask pairs FIRST, then the eight selects.  hipcc compiles the
 // plain form to  v_cmp (vcc), s_nop 1, two v_cndmask  per accumulator -- on gfx950 a VALU instruction that reads a mask must stand two instructions
 // behind the VALU compare that wrote it, and with every compare going through vcc nothing can fill the gap: 16 instructions per event kind and
-// row, 4 of them s_nop.  Here the gaps fill themselves: 12 instructions.
+// row, 4 of them s_nop.  Here the gaps fill themselves: 12 instructions (+ one s_nop 1 in front: the compiler's hazard recogniser does not look into the
+// statement, and `ibit` may reach it fresh from a v_readfirstlane -- an SGPR written by a VALU instruction must be two states old when a VALU compare reads it).
+// gfx950 only, like the rest of the library (Makefile: --offload-arch=gfx950).
 __device__ __forceinline__ void tile_events_start(cb_u32 ibit, const cb_u32 (&sbit)[4], float (&sum)[4], int (&cb)[4], int Pn)
 {
 	unsigned long long m0, m1, m2, m3;
-	asm volatile("v_cmp_eq_u32_e64 %[m0], %[ib], %[b0]\n v_cmp_eq_u32_e64 %[m1], %[ib], %[b1]\n v_cmp_eq_u32_e64 %[m2], %[ib], %[b2]\n v_cmp_eq_u32_e64 %[m3], %[ib], %[b3]\n"
+	asm volatile("s_nop 1\n v_cmp_eq_u32_e64 %[m0], %[ib], %[b0]\n v_cmp_eq_u32_e64 %[m1], %[ib], %[b1]\n v_cmp_eq_u32_e64 %[m2], %[ib], %[b2]\n v_cmp_eq_u32_e64 %[m3], %[ib], %[b3]\n"
 	             " v_cndmask_b32_e64 %[s0], %[s0], 0, %[m0]\n v_cndmask_b32_e64 %[c0], %[c0], %[pn], %[m0]\n"
 	             " v_cndmask_b32_e64 %[s1], %[s1], 0, %[m1]\n v_cndmask_b32_e64 %[c1], %[c1], %[pn], %[m1]\n"
 	             " v_cndmask_b32_e64 %[s2], %[s2], 0, %[m2]\n v_cndmask_b32_e64 %[c2], %[c2], %[pn], %[m2]\n"
@@ -240,7 +242,7 @@ __device__ __forceinline__ void tile_events_start(cb_u32 ibit, const cb_u32 (&sb
 __device__ __forceinline__ void tile_events_end(cb_u32 ibit, const cb_u32 (&ebit)[4], const float (&sum)[4], float (&res)[4], int (&ce)[4], int Pn)
 {
 	unsigned long long m0, m1, m2, m3;
-	asm volatile("v_cmp_eq_u32_e64 %[m0], %[ib], %[b0]\n v_cmp_eq_u32_e64 %[m1], %[ib], %[b1]\n v_cmp_eq_u32_e64 %[m2], %[ib], %[b2]\n v_cmp_eq_u32_e64 %[m3], %[ib], %[b3]\n"
+	asm volatile("s_nop 1\n v_cmp_eq_u32_e64 %[m0], %[ib], %[b0]\n v_cmp_eq_u32_e64 %[m1], %[ib], %[b1]\n v_cmp_eq_u32_e64 %[m2], %[ib], %[b2]\n v_cmp_eq_u32_e64 %[m3], %[ib], %[b3]\n"
 	             " v_cndmask_b32_e64 %[r0], %[r0], %[s0], %[m0]\n v_cndmask_b32_e64 %[c0], %[c0], %[pn], %[m0]\n"
 	             " v_cndmask_b32_e64 %[r1], %[r1], %[s1], %[m1]\n v_cndmask_b32_e64 %[c1], %[c1], %[pn], %[m1]\n"
 	             " v_cndmask_b32_e64 %[r2], %[r2], %[s2], %[m2]\n v_cndmask_b32_e64 %[c2], %[c2], %[pn], %[m2]\n"

@@ -11,6 +11,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <exception>
+#include <new>
 #include <vector>
 #include <zlib.h>
 
@@ -104,8 +106,11 @@ static int read_png16_impl(const char *fname, float *img, int64_t capacity, int 
 		const uint32_t n = be32(hd);
 		// (a chunk cannot be longer than what is left of the file: nothing is allocated for a length a damaged file merely claims)
 		const long left = fp.remaining();
-		if (n > (1u << 30) || (left >= 0 && (unsigned long)left < (unsigned long)n + 4)) {
-			set_error("mc_read_png16: %s: %s", fname, n > (1u << 30) ? "bad chunk length" : "truncated chunk");
+		// (not seekable -- a pipe: the length cannot be checked against the file, so it is bounded by what a chunk of a 16-bit grey image plausibly
+		// holds: encoders write IDAT pieces of 8 KB .. 2 MB; 64 MB is beyond any of them)
+		const uint32_t cap = left >= 0 ? (1u << 30) : (64u << 20);
+		if (n > cap || (left >= 0 && (unsigned long)left < (unsigned long)n + 4)) {
+			set_error("mc_read_png16: %s: %s", fname, n > cap ? "bad chunk length" : "truncated chunk");
 			return MC_EINVAL;
 		}
 		std::vector<unsigned char> d(n + 4);
@@ -219,12 +224,16 @@ int mc_write_pfm(const float *img, int height, int width, const char *fname)
 int mc_read_png16(const char *fname, float *img, int64_t capacity, int *height, int *width)
 {
 	try { return read_png16_impl(fname, img, capacity, height, width); }
-	catch (...) { set_error("mc_read_png16: out of memory reading %s", fname ? fname : "(null)"); return MC_EINVAL; }
+	catch (const std::bad_alloc &) { set_error("mc_read_png16: out of memory reading %s", fname ? fname : "(null)"); return MC_EINVAL; }
+	catch (const std::exception &e) { set_error("mc_read_png16: %s: %s", fname ? fname : "(null)", e.what()); return MC_EINVAL; }
+	catch (...) { set_error("mc_read_png16: %s: unknown exception", fname ? fname : "(null)"); return MC_EINVAL; }
 }
 int mc_write_png16(const float *img, int height, int width, const char *fname)
 {
 	try { return write_png16_impl(img, height, width, fname); }
-	catch (...) { set_error("mc_write_png16: out of memory writing %s", fname ? fname : "(null)"); return MC_EINVAL; }
+	catch (const std::bad_alloc &) { set_error("mc_write_png16: out of memory writing %s", fname ? fname : "(null)"); return MC_EINVAL; }
+	catch (const std::exception &e) { set_error("mc_write_png16: %s: %s", fname ? fname : "(null)", e.what()); return MC_EINVAL; }
+	catch (...) { set_error("mc_write_png16: %s: unknown exception", fname ? fname : "(null)"); return MC_EINVAL; }
 }
 
 // adcensus.grey2jet(grey_img, col_img), adcensus.cu:2000-2053: the jet colour map over val = 4 * grey, doubles, planes red / green / blue.

@@ -25,7 +25,7 @@ def main(d, config):
            "commit": open(cfile).read().strip() if os.path.exists(cfile) else "n/a"}
     # cbca: one ITERATION over one volume = the launches of cbca_by_arms (tile instances + strip kernel, all but one of which
     # stand down at their first instruction): summed, not averaged
-    groups = {"sgm": ("sgm_pass_kernel",), "cbca": ("cbca_strip_kernel", "cbca_tile_kernel", "cbca_lean_kernel", "cbca_lean2x_kernel", "cbca_classify_kernel", "cbca_classify2x_kernel", "cbca_list_kernel", "cbca_list_cost_kernel"),
+    groups = {"sgm": ("sgm_pass_kernel",), "cbca": ("cbca_strip_kernel", "cbca_tile_kernel", "cbca_lean_kernel", "cbca_lean2x_kernel", "cbca_classify_kernel", "cbca_classify2x_kernel", "cbca_list_kernel", "cbca_list_cost_kernel", "cbca_list_reset_kernel"),
               "join": ("join_owner_kernel",),
               "transpose": ("transpose_kernel", "transpose4_kernel")}
     for g, pat in groups.items():
