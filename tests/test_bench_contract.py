@@ -156,3 +156,28 @@ def test_traffic_files_say_where_their_numbers_come_from():
         assert t.get("run") and t.get("commit") and t["commit"] != "n/a", f
         assert src.startswith("profiles/traffic_%s.json" % key) and "not measured in this run" in src and t["commit"] in src
     assert bench.traffic_file("no_such_config") == ({}, None)
+
+
+def test_round6_side_records_are_wired_into_the_default_line():
+    """the image -> disparity record (feature net included) and the pairs-in-flight record ride in the default line, ahead of the long
+    north_star record; the convolution's roofline is priced against the fp32 matrix peak, on the reference's flop count"""
+    import inspect
+    b = _bench()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('"kitti_fast_from_images": fimg') < src.index('"kitti_accurate": kacc') < src.index('"north_star": north')
+    f = inspect.getsource(b.from_images_record)
+    assert "features_fast" in f and "157.3" in f and "2.0 * 2 * H * W * fm * fm * 9" in f
+    assert "conv2d" in f and "verify_against_reference" in f          # checked against a float64 convolution and the reference's kernels
+    p = inspect.getsource(b.pipelined_record)
+    assert "torch.cuda.Stream" in p and "Workspace(" in p and "same_bits_dev" in p
+    assert "--pairs-in-flight" in src
+
+
+def test_conv_plan_splits_banks_that_do_not_fit():
+    """mc_conv3x3's workspace holds the re-laid filter bank: groups x pairs (even) x 64 lanes x 9 taps x tiles of 32 channels"""
+    import mc_cnn_amd as mc
+    lib = mc._lib.lib
+    assert lib.mc_conv3x3_workspace_bytes(64, 64) == 32 * 64 * 9 * 2 * 4            # one group of 64 output channels: 144 KB, resident in LDS
+    assert lib.mc_conv3x3_workspace_bytes(1, 64) == 2 * 64 * 9 * 2 * 4              # the pair count is padded to even
+    assert lib.mc_conv3x3_workspace_bytes(112, 112) == 4 * 56 * 64 * 9 * 1 * 4      # four groups of 32 output channels (126 KB each)
+    assert lib.mc_conv3x3_workspace_bytes(0, 64) == 0 and lib.mc_conv3x3_workspace_bytes(64, 129) == 0

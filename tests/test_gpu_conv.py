@@ -1,4 +1,4 @@
-"""-m gpu: the hand-written 3x3 convolution of the feature net (mc_conv3x3, fp32 MFMA implicit GEMM) against a plain
+"""-m gpu: the hand-written 3x3 convolution of the feature net (mc_conv3x3, fp32 MFMA implicit GEMM, filter bank resident in LDS) against a plain
 fp32 torch convolution (cudnn.SpatialConvolution(n_in, fm, 3, 3, 1, 1, 1, 1) + ReLU, main.lua:681-686, 727-746).
 Tolerance 1e-4 relative to the output scale: the reference's cuDNN algorithm (and summation order) is chosen at run
 time (cudnn.benchmark = true, main.lua:330), so this operator has no bit-exact target."""
@@ -15,8 +15,13 @@ torch = pytest.importorskip("torch")
     (2, 64, 64, 20, 31, False),      # arch fast, last layer: no ReLU before Normalize2
     (2, 112, 112, 18, 45, True),     # arch slow
     (1, 3, 7, 9, 11, True),          # odd everything
-    (2, 16, 128, 8, 40, False),
-    (1, 40, 96, 5, 33, True),
+    (2, 16, 128, 8, 40, False),      # two groups of 64 output channels
+    (1, 40, 96, 5, 33, True),        # three groups of 32
+    (1, 150, 40, 9, 70, True),       # a bank that does not fit even for 32 output channels: chunks of input channels, LDS reloaded
+    (1, 64, 64, 1, 5, True),         # one row, less than a strip
+    (3, 8, 64, 61, 33, False),       # runs that cross columns and images, tiles of 1 .. 4 rows
+    (1, 64, 64, 300, 100, True),     # every wave of the launch busy, several tiles per wave, short last tiles
+    (1, 112, 112, 130, 70, True),    # the same for the four-group split (tiles of 8 rows)
 ])
 def test_conv3x3_vs_torch(mc, N, Cin, Cout, H, W, relu):
     import torch.nn.functional as F

@@ -213,11 +213,12 @@ def test_post_chain(ref, mc, oracle, H, W, D):
         same(host(mc.adcensus.mean2d(rmed, kref.cuda(), t)), host(rmean), "hip mean2d vs reference")
 
 
-def test_normalize_forward(ref, mc, oracle):
-    rng = np.random.default_rng(9)
-    x = rng.standard_normal((2, 64, 11, 23)).astype(np.float32)
+@pytest.mark.parametrize("C", [64, 1, 7, 112, 130])   # 64 / 112: the nets' widths (register-resident instances); 130: the any-width instance
+def test_normalize_forward(ref, mc, oracle, C):
+    rng = np.random.default_rng(9 + C)
+    x = rng.standard_normal((2, C, 11, 23)).astype(np.float32)
     rn = torch.empty((2, 1, 11, 23), device="cuda")
-    rout = torch.empty((2, 64, 11, 23), device="cuda")
+    rout = torch.empty((2, C, 11, 23), device="cuda")
     ref.call("Normalize_forward", dev(x), rn, rout)
     same(oracle.normalize_forward(x), host(rout), "oracle normalize vs reference")
     gn = torch.empty_like(rn)
