@@ -598,7 +598,9 @@ int mc_conv3x3(const float *in, const float *weight, const float *bias, float *o
 	MC_REQUIRE(in && weight && bias && out && workspace && in != out, "mc_conv3x3: bad pointers");
 	MC_REQUIRE(N >= 1 && Cin >= 1 && Cout >= 1 && dims_ok(1, H, W), "mc_conv3x3: bad dims");
 	MC_REQUIRE(Cout <= 128, "mc_conv3x3: Cout=%d exceeds 128 (the nets of main.lua:73-75, 120-122 use 64 and 112)", Cout);
-	MC_REQUIRE(N <= 65535 && (H + 3) / 4 <= 65535, "mc_conv3x3: problem too large for one launch");
+	// 32-bit byte offsets inside one image's planes (buffer addressing) and 32-bit unit counts
+	MC_REQUIRE((int64_t)(Cout > Cin ? Cout : Cin + 1) * H * W * 4 < (int64_t)0xFFFFFF00 && (int64_t)N * ((W + 31) / 32) * H < ((int64_t)1 << 31),
+	           "mc_conv3x3: %d x %d x (%d -> %d channels) x %d images exceeds the kernel's 32-bit offsets", H, W, Cin, Cout, N);
 	MC_REQUIRE(workspace_bytes >= conv3x3_workspace_bytes(Cin, Cout), "mc_conv3x3: workspace %zu < %zu bytes", workspace_bytes,
 	           conv3x3_workspace_bytes(Cin, Cout));
 	MC_REQUIRE((uintptr_t)workspace % 16 == 0, "mc_conv3x3: workspace must be 16-byte aligned");

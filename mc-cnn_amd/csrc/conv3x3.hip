@@ -393,14 +393,16 @@ static int conv_launch(const ConvPlan &p, const float *in, const float *wt, cons
 {
 	constexpr int R = cv_rows(NT);
 	const int lds = p.chunk_pairs * 64 * 9 * NT * (int)sizeof(float);
-	static bool raised = false;
-	if (!raised) {
+	static bool raised[64];                          // the attribute belongs to (function, device)
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+	if (!raised[dev]) {
 		const hipError_t e = hipFuncSetAttribute((const void *)conv3x3_kernel<NT, RELU, CHUNKED>, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES);
 		if (e != hipSuccess) {
 			set_error("conv3x3: hipFuncSetAttribute(%d bytes of LDS): %s", CV_LDS_BYTES, hipGetErrorString(e));
 			return (int)e;
 		}
-		raised = true;
+		raised[dev] = true;
 	}
 	const int64_t T = (int64_t)N * ((W + 31) / 32) * H;                     // (image, strip, row) units
 	const int64_t want = (T + (int64_t)CV_WAVES * R - 1) / ((int64_t)CV_WAVES * R);   // blocks that give every wave a full tile
