@@ -9,7 +9,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
 nproc > $O/nproc.txt
 MC_REQUIRE_REF=1 timeout 1200 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-timeout 600 python bench.py --steps 30 --warmup 3 > $O/bench_kitti_fast.json 2> $O/bench_kitti_fast.err
+timeout 900 python bench.py --steps 30 --warmup 3 > $O/bench_kitti_fast.json 2> $O/bench_kitti_fast.err
 timeout 400 python bench.py --config kitti_slow --steps 20 --warmup 3 > $O/bench_kitti_slow.json 2> $O/bench_kitti_slow.err
 timeout 400 python bench.py --config mb_slow --steps 5 --warmup 2 > $O/bench_mb_slow.json 2> $O/bench_mb_slow.err
 timeout 400 python bench.py --config mb_slow --pair natural --steps 3 --warmup 1 > $O/bench_mb_slow_natural.json 2> $O/bench_mb_slow_natural.err
