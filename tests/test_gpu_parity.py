@@ -455,10 +455,11 @@ def test_predict_kitti_end_to_end(mc, oracle, tmp_path, capsys):
         feat = host(mcmain.features_fast(dev(np.stack([x0, x1])), layers))
         disp = oracle.stereo_predict(prm, x0[0], x1[0], D, featL=feat[0], featR=feat[1])["disp"].reshape(H, W)
         want_errs.append(pk.three_pixel_error(disp, binio.read_png16(str(root / ("training/disp_noc/%06d_10.png" % i)))))
-    assert pk.main(["test", "-path", str(root), "-net_fname", "random:7", "-disp_max", str(D), "-n", "2"]) == 0
-    lines = capsys.readouterr().out.strip().splitlines()
-    assert [float(l.split()[1]) for l in lines[:2]] == want_errs
-    assert abs(float(lines[-1]) - sum(want_errs) / 2) < 1e-12
+    for k in ("1", "2", "3"):   # pairs in flight per rank: the results do not depend on it
+        assert pk.main(["test", "-path", str(root), "-net_fname", "random:7", "-disp_max", str(D), "-n", "2", "-pairs_in_flight", k]) == 0
+        lines = capsys.readouterr().out.strip().splitlines()
+        assert [float(l.split()[1]) for l in lines[:2]] == want_errs
+        assert abs(float(lines[-1]) - sum(want_errs) / 2) < 1e-12
 
 
 def test_errors_are_loud(mc):

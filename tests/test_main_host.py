@@ -308,6 +308,24 @@ def test_predict_kitti_host_logic(tmp_path):
         m = gts[i] != 0
         want += ((left > 128) & m).sum() / m.sum()
     assert abs(total - want) < 1e-12
+    # a staged predictor (submit / result) with pairs in flight: same order, same total
+    class Staged:
+        def __init__(self):
+            self.log = []
+
+        def submit(self, im0, im1):
+            self.log.append(("submit", int(os.path.basename(im0)[:6])))
+            return (im0, im1)
+
+        def result(self, t):
+            self.log.append(("result", int(os.path.basename(t[0])[:6])))
+            return fake_predict(*t)
+
+    st = Staged()
+    seen.clear()
+    total2, done2 = pk.run("test", str(root), st, n_pairs=3, log=lambda *a: None, in_flight=2)
+    assert done2 == 3 and abs(total2 - want) < 1e-12
+    assert st.log == [("submit", 0), ("submit", 1), ("result", 0), ("submit", 2), ("result", 1), ("result", 2)]
     # two ranks split the pairs; each writes its own submission files
     seen.clear()
     for r in (0, 1):
