@@ -52,6 +52,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float *p, u
 	return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// ReLU as ONE v_max_f32: through fmaxf the compiler first quiets an operand it cannot prove quiet (a v_max x, x each).  A NaN sum becomes 0, as with fmaxf.
+__device__ __forceinline__ float relu1(float v)
+{
+	float r;
+	asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+	return r;
+}
+
 // W (Cout, Cin, 3, 3) -> Wt [group][ci pair][lane = kh * 32 + nl][tap][t] = W[co = 32 (group NT + t) + nl][ci = 2 pair + kh][tap],
 // zero padded (channels beyond Cout / Cin, and the pair that makes the pair count even)
 __global__ void __launch_bounds__(256) conv_prep_kernel(const float *__restrict__ w, float *__restrict__ wt, int Cin, int Cout, int npairs, int NT, int groups)
@@ -131,12 +139,25 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(const float *__restrict__ 
 	// the tile at unit `at`: image, first column, first row, rows.  What is left of the run in this column is cut into its
 	// number of tiles EVENLY (29 rows = 4 4 4 4 4 3 3 3, not seven fours and a one): a tile of one row has 18 matrix
 	// instructions per channel pair, too few to cover the next pair's requests
-	auto place = [&](int at, int &n, int &x0, int &y0, int &rows) {
+	// `want` > 0 (the first one or two tiles of a run): that many rows instead -- the four waves of a block start with tiles of different
+	// heights, so that their tile boundaries, i.e. their bursts of R * NT * 16 stores, fall at different quarters of a tile's time for
+	// the rest of the launch.  With every wave of the chip in step the bursts (32 MB together) came at once and the next tile's second
+	// channel pair waited for them to drain.
+	auto place = [&](int at, int &n, int &x0, int &y0, int &rows, int want = 0) {
 		const int col = at / H;
 		const int y = at - col * H, nn = col / S;
 		const int left = min(H - y, end - at), tiles = (left + R - 1) / R;
+		const int even = (left + tiles - 1) / max(tiles, 1);
 		n = __builtin_amdgcn_readfirstlane(nn), x0 = __builtin_amdgcn_readfirstlane((col - nn * S) * 32);
-		y0 = __builtin_amdgcn_readfirstlane(y), rows = __builtin_amdgcn_readfirstlane((left + tiles - 1) / max(tiles, 1));
+		y0 = __builtin_amdgcn_readfirstlane(y), rows = __builtin_amdgcn_readfirstlane((want > 0 && left >= 2 * R) ? want : even);
+	};
+	// heights of a run's first two tiles for the block's wave wv: the boundaries of wave wv lie wv * R / 4 rows ahead of wave 0's
+	// (never a tile of one row: 3 quarters ahead = a tile of 2 rows, then one of R - 1)
+	auto phase_rows = [&](int tile) -> int {
+		const int first = R - wv * (R / 4);
+		if (wv == 0 || tile > 1) return 0;
+		if (first >= 2) return tile == 0 ? first : 0;
+		return tile == 0 ? 2 : R - 1;
 	};
 	// byte offsets, within a pair of channel planes, of the lane's pixel in the R + 2 input rows x 3 column shifts; a
 	// position outside the image gets an offset beyond the buffer, for which the hardware returns 0: the zero padding
@@ -219,6 +240,7 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(const float *__restrict__ 
 		const int ox = x0 + nl;
 		if ((Cout & 7) == 0) {
 			// the eight channels co .. co + 7 of a register quartet exist or not as one: a wave-uniform test, no range check
+			const bool whole = co0 + NT * 32 <= Cout;   // every channel of the group exists (64 of 64; the last group of 112 has 16 of 32)
 			if (ox < W) {
 #pragma unroll
 				for (int r = 0; r < R; ++r) {
@@ -230,11 +252,11 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(const float *__restrict__ 
 #pragma unroll
 						for (int q = 0; q < 4; ++q) {
 							const int cq = co0 + t * 32 + 8 * q;
-							if (cq < Cout) {
+							if (whole || cq < Cout) {
 #pragma unroll
 								for (int j = 0; j < 4; ++j) {
 									const float v = acc[r][t][4 * q + j];
-									__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(RELU ? fmaxf(v, 0.0f) : v), ro, o0, (uint32_t)(cq + j) * plane, 0);
+									__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(RELU ? relu1(v) : v), ro, o0, (uint32_t)(cq + j) * plane, 0);
 								}
 							}
 						}
@@ -257,7 +279,7 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(const float *__restrict__ 
 						// lane that must store (api.hip checks Cout * plane), and a lane holding CV_OOB must stay out of range:
 						// saturate instead of wrapping
 						const uint32_t off = o0 > CV_OOB - cpl ? CV_OOB : o0 + cpl;
-						__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(RELU ? fmaxf(v, 0.0f) : v), ro, off, 0, 0);
+						__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(RELU ? relu1(v) : v), ro, off, 0, 0);
 					}
 				}
 			}
@@ -277,7 +299,8 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(const float *__restrict__ 
 		if (cur >= end) return;
 		int n, x0, y0;
 		uint32_t voff[R + 2][3];
-		place(cur, n, x0, y0, rows);
+		int tile = 0;
+		place(cur, n, x0, y0, rows, phase_rows(0));
 		offsets(x0, y0, voff);
 		fetch(n, voff, 0, 0, b0, a0);
 		__builtin_amdgcn_s_waitcnt(0x0F70);            // the one request of the run that nothing covers
@@ -288,7 +311,8 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(const float *__restrict__ 
 			const bool more = nxt < end;
 			int n2, x2, y2, rows2;
 			uint32_t voff2[R + 2][3];
-			place(more ? nxt : cur, n2, x2, y2, rows2);   // a finished run requests its last tile again, and never uses it
+			++tile;
+			place(more ? nxt : cur, n2, x2, y2, rows2, more ? phase_rows(tile) : 0);   // a finished run requests its last tile again, and never uses it
 			offsets(x2, y2, voff2);
 			// two register sets of operands, used in turn.  The requests are straight-line code (one whose only consumer sits
 			// behind a branch gets sunk into that branch by the compiler, in front of its own wait): the tile's last step
