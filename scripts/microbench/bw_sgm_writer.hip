@@ -168,6 +168,59 @@ __global__ void __launch_bounds__(64 * (LW + 1)) sweep_b(const Args A)
 	}
 }
 
+
+// C: TWO waves per line, each owning half of the pixel's run (8 bytes per lane): twice the waves for the same bytes.  What a split recurrence would
+// have to exchange per step -- its half's minimum and the two values at the seam -- goes through LDS with one block barrier per step (slots
+// alternate by step parity).  The chain per wave is WORKC = 0.4 WORK (per-step part) + 0.3 WORK (per-value part, halved) long.
+template <int U>
+__global__ void __launch_bounds__(128) sweep_c(const Args A)
+{
+	__shared__ float xch[2][2][4];
+	const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	int wave = blockIdx.x;
+	const int nh = A.nvol * A.H, nsteps = A.W;
+	if (wave >= 2 * nh) return;
+	const bool second = wave >= nh;
+	if (second) wave -= nh;
+	const int dirn = second ? 1 : 0, v = wave / A.H, ln = wave % A.H;
+	const int half = ((A.ds / 2) + 1) & ~1;            // floats per wave (even)
+	const int f0 = h * half + lane * 2;                // this lane's first float inside the run
+	const bool act = lane * 2 < half && f0 < A.ds;
+	const float *c = A.c + v * A.vol;
+	float *out = (second ? A.out2 : A.out) + v * A.vol;
+	typedef float f2 __attribute__((ext_vector_type(2)));
+	auto off = [&](int s) -> size_t {
+		const int x = dirn == 0 ? s : A.W - 1 - s;
+		return ((size_t)ln * A.W + x) * A.ds + (act ? f0 : 0);
+	};
+	f2 rc[U];
+#pragma unroll
+	for (int u = 0; u < U; ++u) rc[u] = __builtin_nontemporal_load((const f2 *)(c + off(u)));
+	float carry = 0.0f;
+	const int workc = (A.work * 7 + 9) / 10;
+	for (int g = 0; g < nsteps; g += U) {
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int s = g + u;
+			f2 t = rc[u];
+			float w = carry + t.x;
+			for (int k = 0; k < workc; ++k) {
+				w = fminf(w, t.y) + t.x;
+				asm volatile("" : "+v"(w));
+			}
+			// the exchange: this half's minimum (here: w) and seam values to the other wave, theirs back
+			if (lane == 0) { xch[s & 1][h][0] = w; xch[s & 1][h][1] = t.x; xch[s & 1][h][2] = t.y; }
+			__syncthreads();
+			const float pw = xch[s & 1][1 - h][0], px = xch[s & 1][1 - h][1];
+			carry = fminf(w, pw) + px * 0.0f;
+			t.x += carry;
+			if (s < nsteps && act) __builtin_nontemporal_store(t, (f2 *)(out + off(s)));
+			const int sn = s + U;
+			rc[u] = __builtin_nontemporal_load((const f2 *)(c + off(sn < nsteps ? sn : nsteps - 1)));
+		}
+	}
+}
+
 template <typename F> float timeit(F f, int reps)
 {
 	hipEvent_t e0, e1;
@@ -200,7 +253,7 @@ int main(int argc, char **argv)
 	const double V = (double)vol * 4 * nvol / 1e9;
 	printf("H=%d W=%d D=%d ds=%d, %d volumes: %.3f GB per stream, the launch moves %.3f GB; ms per launch\n", H, W, D, ds, nvol, V, 4 * V);
 	printf("%-5s | %-9s | %-28s | %-28s | %-28s\n", "work", "A (today)", "B LW 3, ring 16 / 32", "B LW 7, ring 8 / 16", "B LW 1 / LW 15 ring 8");
-	for (int work : {0, 20, 45, 70}) {
+	for (int work : {0, 5, 10, 20, 45}) {
 		Args A;
 		A.c = buf[0]; A.out = buf[1]; A.out2 = buf[2];
 		A.H = H; A.W = W; A.ds = ds; A.nvol = nvol; A.work = work; A.vol = vol;
@@ -227,8 +280,10 @@ int main(int argc, char **argv)
 		const float tb3 = timeit([&] { hipLaunchKernelGGL((sweep_b<8, 7, 16>), dim3((nl + 6) / 7), dim3(512), 0, 0, A); }, 10);
 		const float tb4 = timeit([&] { hipLaunchKernelGGL((sweep_b<8, 1, 16>), dim3(nl), dim3(128), 0, 0, A); }, 10);
 		const float tb5 = timeit([&] { hipLaunchKernelGGL((sweep_b<8, 15, 8>), dim3((nl + 14) / 15), dim3(1024), 0, 0, A); }, 10);
+		const float tc0 = timeit([&] { hipLaunchKernelGGL((sweep_c<8>), dim3(nl), dim3(128), 0, 0, A); }, 10);
+		const float tc1 = timeit([&] { hipLaunchKernelGGL((sweep_c<16>), dim3(nl), dim3(128), 0, 0, A); }, 10);
 		CK(hipGetLastError());
-		printf("%-5d | %9.3f | %13.3f %13.3f  | %13.3f %13.3f  | %13.3f %13.3f\n", work, ta, tb0, tb1, tb2, tb3, tb4, tb5);
+		printf("%-5d | %9.3f | %13.3f %13.3f  | %13.3f %13.3f  | %13.3f %13.3f | C (two waves per line, U 8 / 16) %8.3f %8.3f\n", work, ta, tb0, tb1, tb2, tb3, tb4, tb5, tc0, tc1);
 	}
 	return 0;
 }
