@@ -425,6 +425,18 @@ def sub_record(device, config, reps=10, pair=None):
     return rec
 
 
+def conv_pmc():
+    """the convolution's matrix-pipe counters from the builder's PMC pass (they cannot be collected inside a timed run), labelled as such"""
+    path = os.path.join(ROOT, "profiles", "conv3x3_mfma_busy.json")
+    try:
+        j = json.load(open(path))
+        k = j["kitti_64"]
+        return dict(mfma_busy_frac_of_launch=k["mfma_busy_frac_of_launch"], clock_GHz_while_profiled=k["clock_GHz_while_profiled"],
+                    mfma_busy_source="profiles/conv3x3_mfma_busy.json: builder's PMC pass of %s (commit %s), not measured in this run" % (j["run"], j["commit"]))
+    except Exception:
+        return dict(mfma_busy_frac_of_launch=None)
+
+
 def from_images_record(device, reps=20):
     """KITTI-2012 fast from the IMAGES (main.lua:1084-1100 starts at the PNGs): normalised (2,1,370,1226) pair -> feature net
     (4 x mc_conv3x3 + mc_normalize_forward, seeded weights resident on the device) -> mc_predict.  Per-stage HIP-event times on the launch
@@ -497,7 +509,7 @@ def from_images_record(device, reps=20):
                roofline=dict(bound="mfma", kernel="conv3x3_kernel<2> (64->64, both images per launch; resident filter bank, v_mfma_f32_32x32x2_f32)",
                              achieved=round(tf, 1), peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4), traffic=None,
                              algorithmic_flops_per_launch=flop, avg_launch_ms=round(float(np.mean(inner)), 4),
-                             note="flops = 2*N*H*W*Cin*Cout*9; launch time includes the 5 us re-layout of the weights"),
+                             note="flops = 2*N*H*W*Cin*Cout*9; launch time includes the 5 us re-layout of the weights", **conv_pmc()),
                features_max_abs_err_vs_float64=err, features_tolerance=1e-4, features_ok=bool(err <= 1e-4),
                verify=dict(bit_exact=ver.get("bit_exact"), available=ver.get("available"),
                            note="mc_predict on these features against the reference's kernels on the same features"))
